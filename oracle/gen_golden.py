@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the IMPORTED reference networks.
+
+Runs only in the build container (needs /root/reference).  The reference is
+imported read-only from where it lies (PYTHONDONTWRITEBYTECODE=1, nothing is
+copied); five third-party packages that the hot path never calls are replaced
+by empty stub modules.  What is committed is DATA only: seeded
+inputs, outputs, gradients and state-dict key/shape lists.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference/code"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import init as oinit  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    _stub("fvcore"); _stub("fvcore.nn"); _stub("fvcore.nn.weight_init")
+    sys.modules["fvcore"].nn = sys.modules["fvcore.nn"]
+    sys.modules["fvcore.nn"].weight_init = sys.modules["fvcore.nn.weight_init"]
+    _stub("thop", clever_format=None, profile=None)
+    _stub("torchsummary", summary=None)
+    _stub("detectron2"); _stub("detectron2.config", configurable=lambda f: f)
+    _stub("detectron2.utils"); _stub("detectron2.utils.registry", Registry=lambda n: None)
+    _stub("timm"); _stub("timm.models")
+    _stub("timm.models.layers", DropPath=None, trunc_normal_=None, trunc_normal_tf_=None, to_2tuple=None)
+    sys.path.insert(0, REF)
+    from networks.unet import DualDecoder, UNet
+    from networks.vnet import DualDecoder3d, VNet
+    from networks.unet_3D import unet_3D
+    from networks.FilterDropout import perform_dropout
+    return dict(DualDecoder=DualDecoder, UNet=UNet, DualDecoder3d=DualDecoder3d, VNet=VNet,
+                unet_3D=unet_3D, perform_dropout=perform_dropout)
+
+
+class Injected(nn.Module):
+    """Stands in for nn.Dropout / nn.Dropout3d on a *live reference instance* so the
+    reference runs with a known keep mask (same inverted-dropout scaling)."""
+
+    def __init__(self, keep, p):
+        super().__init__()
+        self.keep, self.p = keep, p
+
+    def forward(self, x):
+        if not self.training:
+            return x
+        k = self.keep.to(x.dtype)
+        while k.dim() < x.dim():
+            k = k.unsqueeze(-1)
+        return x * k / (1.0 - self.p)
+
+
+def _np(t):
+    a = t.detach().cpu().numpy()
+    # fp64 truth runs are stored rounded to fp32 (6e-8 rel): half the fixture bytes
+    return a.astype(np.float32) if a.dtype == np.float64 and a.size > 16 else a
+
+
+def _checks(named):
+    """per-tensor (sum, abs-sum) table, float64."""
+    return np.array([[float(t.double().sum()), float(t.double().abs().sum())] for _, t in named], dtype=np.float64)
+
+
+def run_case(model, x, cot_seed, train, dtype=torch.float32):
+    """forward (+ backward against a fixed random cotangent) -> dict of arrays."""
+    model.train(train)
+    model.to(dtype)
+    x = x.clone().to(dtype).requires_grad_(True)
+    outs = model(x)
+    outs = outs if isinstance(outs, (tuple, list)) else (outs,)
+    g = torch.Generator().manual_seed(cot_seed)
+    loss = 0
+    for o in outs:
+        loss = loss + (o * torch.randn(o.shape, generator=g).to(dtype)).sum()
+    model.zero_grad()
+    loss.backward()
+    res = {"logits%d" % i: _np(o) for i, o in enumerate(outs)}
+    res["loss"] = np.float64(loss.item())
+    res["dx"] = _np(x.grad)
+    params = list(model.named_parameters())
+    res["grad_checks"] = _checks([(n, p.grad) for n, p in params])
+    return res, params
+
+
+def gen_2d(ref):
+    torch.manual_seed(0)
+    N, H, W = 2, 64, 64
+    sd = oinit.dual_decoder_2d_state(101)
+    m = ref["DualDecoder"](1, 4, {"decoder_type": "mcnet"})
+    m.load_state_dict(sd, strict=True)          # pins key names + shapes
+    x = torch.rand(N, 1, H, W, generator=torch.Generator().manual_seed(7))
+    out = {"x": _np(x), "state_seed": 101, "cot_seed": 11, "mask_seed": 21,
+           "keys": np.array(list(m.state_dict().keys())),
+           "shapes": np.array([str(tuple(v.shape)) for v in m.state_dict().values()]),
+           "param_names": np.array([n for n, _ in m.named_parameters()])}
+    r, params = run_case(m, x, 11, train=False)
+    out.update({"eval_" + k: v for k, v in r.items()})
+    pick = ["encoder.in_conv.conv_conv.0.weight", "encoder.in_conv.conv_conv.1.weight",
+            "encoder.down2.maxpool_conv.1.conv_conv.4.weight", "decoder1.up1.conv1x1.weight",
+            "decoder2.up3.up.weight", "decoder2.up3.up.bias", "decoder1.out_conv.weight",
+            "decoder2.up4.conv.conv_conv.5.bias", "encoder.down4.maxpool_conv.1.conv_conv.0.bias"]
+    out["grad_pick_names"] = np.array(pick)
+    pd = dict(params)
+    for i, n in enumerate(pick):
+        out["eval_grad_pick%d" % i] = _np(pd[n].grad)
+    # train mode, injected dropout masks, BN batch stats + running-stat update
+    masks = oinit.drop_masks_2d(21, N, H, W)
+    blocks = [m.encoder.in_conv] + [getattr(m.encoder, "down%d" % i).maxpool_conv[1] for i in range(1, 5)]
+    for (site, keep), blk, p in zip(masks.items(), blocks, (0.05, 0.1, 0.2, 0.3, 0.5)):
+        blk.conv_conv[3] = Injected(keep, p)
+    r, params = run_case(m, x, 11, train=True)
+    out.update({"train_" + k: v for k, v in r.items()})
+    pd = dict(params)
+    for i, n in enumerate(pick):
+        out["train_grad_pick%d" % i] = _np(pd[n].grad)
+    sd_after = m.state_dict()
+    for k in ("encoder.in_conv.conv_conv.1", "encoder.down3.maxpool_conv.1.conv_conv.5", "decoder2.up4.conv.conv_conv.1"):
+        out["after_rm_" + k] = _np(sd_after[k + ".running_mean"])
+        out["after_rv_" + k] = _np(sd_after[k + ".running_var"])
+    # the same train-mode case in float64: fp32 train-mode gradients through tiny-batch BN are
+    # ill-conditioned (~1e-2 rel), so the algorithm is pinned in fp64 and fp32 paths are judged
+    # by their distance to this fp64 truth.
+    m64 = ref["DualDecoder"](1, 4, {"decoder_type": "mcnet"})
+    m64.load_state_dict(oinit.dual_decoder_2d_state(101), strict=True)
+    blocks = [m64.encoder.in_conv] + [getattr(m64.encoder, "down%d" % i).maxpool_conv[1] for i in range(1, 5)]
+    for (site, keep), blk, p in zip(masks.items(), blocks, (0.05, 0.1, 0.2, 0.3, 0.5)):
+        blk.conv_conv[3] = Injected(keep, p)
+    r, params = run_case(m64, x, 11, train=True, dtype=torch.float64)
+    out.update({"train64_" + k: v for k, v in r.items()})
+    pd = dict(params)
+    for i, n in enumerate(pick):
+        out["train64_grad_pick%d" % i] = _np(pd[n].grad)
+    np.savez_compressed(os.path.join(OUT, "dualdecoder2d_64.npz"), **out)
+
+    # full-size (config-1 shape) eval logits, subsampled, N=1
+    m2 = ref["DualDecoder"](1, 4, {"decoder_type": "mcnet"})
+    m2.load_state_dict(oinit.dual_decoder_2d_state(101), strict=True)
+    m2.eval()
+    x = torch.rand(1, 1, 256, 256, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        o1, o2 = m2(x)
+    np.savez_compressed(os.path.join(OUT, "dualdecoder2d_256.npz"), x_seed=8, state_seed=101,
+                        logits0_sub=_np(o1[:, :, ::4, ::4]), logits1_sub=_np(o2[:, :, ::4, ::4]),
+                        sums=np.array([o1.double().sum().item(), o2.double().sum().item(),
+                                       o1.double().abs().sum().item(), o2.double().abs().sum().item()]))
+
+    # plain UNet (net_type='unet')
+    mu = ref["UNet"](1, 4)
+    mu.load_state_dict(oinit.unet_2d_state(103), strict=True)
+    x = torch.rand(2, 1, 32, 32, generator=torch.Generator().manual_seed(9))
+    r, _ = run_case(mu, x, 12, train=False)
+    np.savez_compressed(os.path.join(OUT, "unet2d_32.npz"), x=_np(x), state_seed=103, cot_seed=12,
+                        keys=np.array(list(mu.state_dict().keys())), **{"eval_" + k: v for k, v in r.items()})
+
+    # default-init recipe: manual_seed(1337) then construct (code/train_ours_2D.py:487,551)
+    torch.manual_seed(1337)
+    md = ref["DualDecoder"](1, 4, {"decoder_type": "mcnet"})
+    np.savez_compressed(os.path.join(OUT, "dualdecoder2d_init1337.npz"),
+                        keys=np.array(list(md.state_dict().keys())),
+                        checks=_checks(list(md.state_dict().items())))
+
+
+def gen_3d(ref):
+    N, D, H, W = 1, 32, 32, 16
+    sd = oinit.dual_decoder_3d_state(201)
+    m = ref["DualDecoder3d"](n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)
+    m.load_state_dict(sd, strict=True)
+    x = torch.rand(N, 1, D, H, W, generator=torch.Generator().manual_seed(17))
+    out = {"x": _np(x), "state_seed": 201, "cot_seed": 31, "mask_seed": 41,
+           "keys": np.array(list(m.state_dict().keys())),
+           "shapes": np.array([str(tuple(v.shape)) for v in m.state_dict().values()]),
+           "param_names": np.array([n for n, _ in m.named_parameters()])}
+    r, params = run_case(m, x, 31, train=False)
+    out.update({"eval_" + k: v for k, v in r.items()})
+    pick = ["encoder.block_one.conv.0.weight", "encoder.block_two_dw.conv.0.weight",
+            "decoder1.block_seven_up.conv.1.weight", "decoder2.block_seven_up.conv.0.weight",
+            "decoder2.block_nine.conv.1.weight", "decoder1.out_conv.weight"]
+    out["grad_pick_names"] = np.array(pick)
+    pd = dict(params)
+    for i, n in enumerate(pick):
+        out["eval_grad_pick%d" % i] = _np(pd[n].grad)
+    N2 = 2
+    x2 = torch.rand(N2, 1, D, H, W, generator=torch.Generator().manual_seed(18))
+    masks = oinit.drop_masks_3d(41, N2)
+    m.encoder.dropout = Injected(masks["encoder.dropout"], 0.5)
+    m.decoder1.dropout = Injected(masks["decoder1.dropout"], 0.5)
+    m.decoder2.dropout = Injected(masks["decoder2.dropout"], 0.5)
+    r, params = run_case(m, x2, 31, train=True)
+    out["x_train"] = _np(x2)
+    out.update({"train_" + k: v for k, v in r.items()})
+    pd = dict(params)
+    for i, n in enumerate(pick):
+        out["train_grad_pick%d" % i] = _np(pd[n].grad)
+    sd_after = m.state_dict()
+    for k in ("encoder.block_one.conv.1", "decoder1.block_six_up.conv.2", "decoder2.block_eight_up.conv.1"):
+        out["after_rm_" + k] = _np(sd_after[k + ".running_mean"])
+        out["after_rv_" + k] = _np(sd_after[k + ".running_var"])
+    m64 = ref["DualDecoder3d"](n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)
+    m64.load_state_dict(oinit.dual_decoder_3d_state(201), strict=True)
+    m64.encoder.dropout = Injected(masks["encoder.dropout"], 0.5)
+    m64.decoder1.dropout = Injected(masks["decoder1.dropout"], 0.5)
+    m64.decoder2.dropout = Injected(masks["decoder2.dropout"], 0.5)
+    r, params = run_case(m64, x2, 31, train=True, dtype=torch.float64)
+    out.update({"train64_" + k: v for k, v in r.items()})
+    pd = dict(params)
+    for i, n in enumerate(pick):
+        out["train64_grad_pick%d" % i] = _np(pd[n].grad)
+    np.savez_compressed(os.path.join(OUT, "dualdecoder3d_32.npz"), **out)
+
+    mv = ref["VNet"](n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=False)
+    mv.load_state_dict(oinit.vnet_state(203), strict=True)
+    x = torch.rand(1, 1, 16, 16, 16, generator=torch.Generator().manual_seed(19))
+    r, _ = run_case(mv, x, 32, train=False)
+    np.savez_compressed(os.path.join(OUT, "vnet_16.npz"), x=_np(x), state_seed=203, cot_seed=32,
+                        keys=np.array(list(mv.state_dict().keys())), **{"eval_" + k: v for k, v in r.items()})
+
+    mu = ref["unet_3D"](n_classes=2, in_channels=1)
+    mu.load_state_dict(oinit.unet_3d_state(205), strict=True)
+    mu.eval()
+    x = torch.rand(1, 1, 32, 32, 32, generator=torch.Generator().manual_seed(20))
+    with torch.no_grad():
+        o = mu(x)
+    np.savez_compressed(os.path.join(OUT, "unet3d_32.npz"), x=_np(x), state_seed=205,
+                        keys=np.array(list(mu.state_dict().keys())), eval_logits0=_np(o))
+
+    torch.manual_seed(1337)
+    md = ref["DualDecoder3d"](n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)
+    np.savez_compressed(os.path.join(OUT, "dualdecoder3d_init1337.npz"),
+                        keys=np.array(list(md.state_dict().keys())),
+                        checks=_checks(list(md.state_dict().items())))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = import_reference()
+    gen_2d(ref)
+    gen_3d(ref)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
