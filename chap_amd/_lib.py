@@ -1,0 +1,195 @@
+"""ctypes binding of libchap_hip.so (the C ABI declared in include/chap_hip.h).
+
+This file is the "reference-side binding a maintainer would add" (INTEGRATION.md): the
+reference is pure Python, so its FFI is ctypes.  Structures mirror the header field by field.
+There is NO fallback: if the library is missing, `lib()` raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libchap_hip.so")
+
+F32, BF16 = 0, 1
+PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_DECONV_FWD, PACK_DECONV_DGRAD, PACK_DOWN_DGRAD = range(5)
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class Src(C.Structure):
+    _fields_ = [("ptr", _vp), ("scale", _vp), ("shift", _vp), ("keep", _vp), ("chan_mul", _vp),
+                ("C", _i32), ("ld", _i32), ("coff", _i32), ("act", _i32), ("slope", _f32), ("keep_scale", _f32)]
+
+
+class ConvParams(C.Structure):
+    _fields_ = [("src", Src * 2), ("nsrc", _i32), ("combine", _i32),
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("ID", _i32), ("IH", _i32), ("IW", _i32),
+                ("ksize", _i32), ("stride", _i32), ("dims", _i32),
+                ("wpacked", _vp), ("bias", _vp), ("out", _vp),
+                ("Cout", _i32), ("out_ld", _i32), ("out_coff", _i32), ("out_mode", _i32), ("out_Cn", _i32),
+                ("out_planar", _i32), ("out_f32", _i32),
+                ("stats", _vp), ("stats_reps", _i32), ("dtype", _i32)]
+
+
+class PackParams(C.Structure):
+    _fields_ = [("w", _vp), ("out", _vp), ("kind", _i32), ("Cin", _i32), ("Cout", _i32), ("taps", _i32), ("dtype", _i32)]
+
+
+class ConvC1Params(C.Structure):
+    _fields_ = [("x", _vp), ("w", _vp), ("bias", _vp), ("out", _vp), ("stats", _vp), ("stats_reps", _i32),
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("dims", _i32), ("Cout", _i32), ("dtype", _i32)]
+
+
+class ConvC1BwdParams(C.Structure):
+    _fields_ = [("g", _vp), ("w", _vp), ("x", _vp), ("dx", _vp), ("dw", _vp), ("db", _vp), ("ws", _vp),
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("dims", _i32), ("Cout", _i32), ("dtype", _i32)]
+
+
+class WgradParams(C.Structure):
+    _fields_ = [("a", Src * 2), ("na", _i32), ("combine", _i32), ("b", Src),
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("ID", _i32), ("IH", _i32), ("IW", _i32),
+                ("ksize", _i32), ("stride", _i32), ("dims", _i32),
+                ("dw", _vp), ("s_tap", _i64), ("s_kc", _i64), ("s_kn", _i64), ("flip", _i32),
+                ("db", _vp), ("ws", _vp), ("ws_bytes", _sz), ("dtype", _i32)]
+
+
+class BnFinalizeParams(C.Structure):
+    _fields_ = [("stats", _vp), ("stats_reps", _i32), ("gamma", _vp), ("beta", _vp),
+                ("running_mean", _vp), ("running_var", _vp), ("num_batches_tracked", _vp),
+                ("scale", _vp), ("shift", _vp), ("mean", _vp), ("invstd", _vp),
+                ("C", _i32), ("count", _f32), ("eps", _f32), ("momentum", _f32)]
+
+
+class BnEvalParams(C.Structure):
+    _fields_ = [("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
+                ("scale", _vp), ("shift", _vp), ("C", _i32), ("eps", _f32)]
+
+
+class ActBwdParams(C.Structure):
+    _fields_ = [("g", _vp * 3), ("g_ld", _i32 * 3), ("g_coff", _i32 * 3), ("ng", _i32),
+                ("g_pool", _vp), ("pool_idx", _vp), ("r", Src),
+                ("mean", _vp), ("invstd", _vp), ("gamma", _vp), ("sums", _vp), ("gout", _vp),
+                ("dgamma", _vp), ("dbeta", _vp),
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("bn", _i32), ("count", _f32), ("dtype", _i32)]
+
+
+class PoolParams(C.Structure):
+    _fields_ = [("r", Src), ("out", _vp), ("idx", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("dtype", _i32)]
+
+
+class UpsampleParams(C.Structure):
+    _fields_ = [("r", Src), ("out", _vp), ("out_ld", _i32), ("out_coff", _i32),
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("dims", _i32), ("dtype", _i32)]
+
+
+class UpsampleBwdParams(C.Structure):
+    _fields_ = [("g", _vp), ("g_ld", _i32), ("g_coff", _i32), ("out", _vp),
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("C", _i32), ("dims", _i32), ("dtype", _i32)]
+
+
+class PlanarToClParams(C.Structure):
+    _fields_ = [("in_", _vp), ("out", _vp), ("N", _i32), ("C", _i32), ("P", _i32), ("out_ld", _i32), ("out_coff", _i32), ("dtype", _i32)]
+
+
+class ClToPlanarParams(C.Structure):
+    _fields_ = [("r", Src), ("out", _vp), ("N", _i32), ("P", _i32), ("dtype", _i32)]
+
+
+class MixLossParams(C.Structure):
+    _fields_ = [("logits", _vp), ("target_a", _vp), ("target_b", _vp), ("mask", _vp), ("w_a", _f32), ("w_b", _f32),
+                ("acc", _vp), ("loss", _vp), ("dlogits", _vp), ("gscale", _f32), ("accumulate", _i32),
+                ("N", _i32), ("C", _i32), ("P", _i32), ("smooth", _f32)]
+
+
+class PseudoParams(C.Structure):
+    _fields_ = [("logits1", _vp), ("logits2", _vp), ("soft1", _vp), ("soft2", _vp), ("arg1", _vp), ("arg2", _vp),
+                ("knowledge", _vp), ("N", _i32), ("C", _i32), ("P", _i32)]
+
+
+class KlParams(C.Structure):
+    _fields_ = [("logits", _vp * 2), ("target", _vp * 2), ("loss", _vp), ("dlogits", _vp * 2),
+                ("gscale", _f32), ("N", _i32), ("C", _i32), ("P", _i32)]
+
+
+class L2NormParams(C.Structure):
+    _fields_ = [("in_", _vp), ("out", _vp), ("N", _i32), ("P", _i32), ("eps", _f32)]
+
+
+class AxpyParams(C.Structure):
+    _fields_ = [("x", _vp), ("d", _vp), ("mask", _vp), ("out", _vp), ("alpha", _f32), ("sign", _i32), ("n", _i64)]
+
+
+class RandParams(C.Structure):
+    _fields_ = [("out", _vp), ("seed", C.c_uint64), ("n", _i64), ("lo", _f32), ("hi", _f32)]
+
+
+class KeepMaskParams(C.Structure):
+    _fields_ = [("keep", _vp), ("seed", C.c_uint64), ("n", _i64), ("p", _f32)]
+
+
+class SgdParams(C.Structure):
+    _fields_ = [("param", _vp), ("grad", _vp), ("mom", _vp), ("lr", _vp), ("momentum", _f32), ("weight_decay", _f32),
+                ("grad_scale", _f32), ("n", _i64), ("first", _i32)]
+
+
+_SIGS = {  # name -> (restype, params struct or None)
+    "chap_conv_fwd": ConvParams, "chap_pack_weights": PackParams, "chap_conv_c1_fwd": ConvC1Params,
+    "chap_conv_c1_bwd": ConvC1BwdParams, "chap_wgrad": WgradParams, "chap_bn_finalize": BnFinalizeParams,
+    "chap_bn_eval_affine": BnEvalParams, "chap_act_bwd_reduce": ActBwdParams, "chap_act_bwd_apply": ActBwdParams,
+    "chap_act_pool2": PoolParams, "chap_upsample2x": UpsampleParams, "chap_upsample2x_bwd": UpsampleBwdParams,
+    "chap_planar_to_cl": PlanarToClParams, "chap_cl_to_planar": ClToPlanarParams,
+    "chap_mix_loss_fwd": MixLossParams, "chap_mix_loss_bwd": MixLossParams, "chap_pseudo_block": PseudoParams,
+    "chap_kl_fwd_bwd": KlParams, "chap_l2_normalize": L2NormParams, "chap_perturb": AxpyParams,
+    "chap_rand_uniform": RandParams, "chap_keep_mask": KeepMaskParams, "chap_sgd_step": SgdParams,
+}
+_SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParams, "chap_wgrad_ws": WgradParams}
+
+_lib = None
+
+
+class ChapError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libchap_hip.so once.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ChapError("libchap_hip.so not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "or `make -C chap_amd/csrc`.  chap_amd has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.chap_last_error.restype = C.c_char_p
+        L.chap_abi_version.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+_bound = {}
+
+
+def _fn(name):
+    """Bind an entry point on first use (argtypes from the tables above)."""
+    fn = _bound.get(name)
+    if fn is None:
+        L = lib()
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            raise ChapError("libchap_hip.so does not export %s (stale build?)" % name)
+        if name in _SIGS:
+            fn.restype, fn.argtypes = C.c_int, [C.POINTER(_SIGS[name]), _vp]
+        else:
+            fn.restype, fn.argtypes = _sz, [C.POINTER(_SIZE_FNS[name])]
+        _bound[name] = fn
+    return fn
+
+
+def call(name, params, stream):
+    rc = _fn(name)(C.byref(params), _vp(stream))
+    if rc != 0:
+        raise ChapError("%s failed (%d): %s" % (name, rc, lib().chap_last_error().decode()))
+
+
+def size_of(name, params):
+    return int(_fn(name)(C.byref(params)))

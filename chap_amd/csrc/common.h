@@ -1,0 +1,110 @@
+// Shared device helpers for libchap_hip.so (gfx950 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "chap_hip.h"
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8;   // 8 x bf16 MFMA operand (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+void chap_set_error(const char* fmt, ...);
+#define CHAP_CHECK_ARG(cond, ...) do { if (!(cond)) { chap_set_error(__VA_ARGS__); return CHAP_EINVAL; } } while (0)
+#define CHAP_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+    chap_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return CHAP_ELAUNCH; } } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;                       // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+template <typename T> struct elem;
+template <> struct elem<float> {
+    static __device__ __forceinline__ float get(float v) { return v; }
+    static __device__ __forceinline__ float put(float v) { return v; }
+};
+template <> struct elem<bf16_t> {
+    static __device__ __forceinline__ float get(bf16_t v) { return bf2f(v); }
+    static __device__ __forceinline__ bf16_t put(float v) { return f2bf(v); }
+};
+
+// 8 consecutive elements <-> 8 floats (16-B aligned for bf16, 32-B for fp32)
+__device__ __forceinline__ void ld8(const float* p, float v[8]) {
+    float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float v[8]) {
+    uint4 a = *(const uint4*)p;
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+}
+__device__ __forceinline__ void st8(float* p, const float v[8]) {
+    *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ void st8(bf16_t* p, const float v[8]) {
+    *(uint4*)p = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+}
+__device__ __forceinline__ void st4(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void st4(bf16_t* p, const float v[4]) { *(uint2*)p = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3])); }
+__device__ __forceinline__ void ld4(const float* p, float v[4]) { float4 a = *(const float4*)p; v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+__device__ __forceinline__ void ld4(const bf16_t* p, float v[4]) {
+    uint2 a = *(const uint2*)p;
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+}
+
+// Load 8 channels [c8, c8+8) of pixel `pix` (global pixel index, sample `n`) of a lazy activation.
+template <typename T>
+__device__ __forceinline__ void src_load8(const chap_src_t& s, int n, long pix, int c8, float v[8]) {
+    ld8((const T*)s.ptr + pix * s.ld + s.coff + c8, v);
+    if (s.scale) {
+        float a[8], b[8];
+        ld8(s.scale + c8, a); ld8(s.shift + c8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], a[j], b[j]);
+    }
+    if (s.act) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * s.slope;
+    }
+    if (s.keep) {
+        uint2 m = *(const uint2*)(s.keep + pix * s.C + c8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            uint32_t w = j < 4 ? m.x : m.y;
+            v[j] = ((w >> (8 * (j & 3))) & 0xff) ? v[j] * s.keep_scale : 0.f;
+        }
+    }
+    if (s.chan_mul) {
+        float a[8];
+        ld8(s.chan_mul + (long)n * s.C + c8, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= a[j];
+    }
+}
+
+// Scalar version (one channel) for element-wise kernels.
+template <typename T>
+__device__ __forceinline__ float src_load1(const chap_src_t& s, int n, long pix, int c) {
+    float v = elem<T>::get(((const T*)s.ptr)[pix * s.ld + s.coff + c]);
+    if (s.scale) v = fmaf(v, s.scale[c], s.shift[c]);
+    if (s.act) v = v > 0.f ? v : v * s.slope;
+    if (s.keep) v = s.keep[pix * s.C + c] ? v * s.keep_scale : 0.f;
+    if (s.chan_mul) v *= s.chan_mul[(long)n * s.C + c];
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

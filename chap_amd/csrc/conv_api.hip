@@ -1,0 +1,128 @@
+// chap_conv_fwd / chap_pack_weights: argument checks, blocking choice, weight packing kernel.
+#include "common.h"
+
+int chap_conv_launch_bf16(const chap_conv_params* p, int KC, int NT, hipStream_t s);
+int chap_conv_launch_f32(const chap_conv_params* p, int KC, int NT, hipStream_t s);
+
+struct conv_blocking { int KC, GPT, NP, STEPS, nchunks, ntiles; };
+
+// K-side geometry shared by the packer and the kernel: Ck = GEMM-K channels, taps = kernel taps.
+static conv_blocking blocking_for(int Ck, int taps, int Cout_logical) {
+    conv_blocking b;
+    b.KC = Ck >= 32 ? 32 : 16;
+    b.GPT = b.KC / 8;
+    b.NP = taps * b.GPT;
+    b.STEPS = (b.NP + 3) / 4;
+    b.nchunks = Ck / b.KC;
+    b.ntiles = (Cout_logical + 15) / 16;
+    return b;
+}
+
+static int check_src(const chap_src_t& s, const char* what) {
+    CHAP_CHECK_ARG(s.ptr != nullptr, "%s: null tensor", what);
+    CHAP_CHECK_ARG(s.C > 0 && s.C % 8 == 0, "%s: C=%d must be a positive multiple of 8", what, s.C);
+    CHAP_CHECK_ARG(s.ld >= s.coff + s.C && s.ld % 8 == 0 && s.coff % 8 == 0, "%s: ld=%d coff=%d C=%d not 8-aligned / too small", what, s.ld, s.coff, s.C);
+    CHAP_CHECK_ARG((s.scale == nullptr) == (s.shift == nullptr), "%s: scale and shift must come together", what);
+    return CHAP_OK;
+}
+
+extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
+    CHAP_CHECK_ARG(p != nullptr, "chap_conv_fwd: null params");
+    CHAP_CHECK_ARG(p->nsrc == 1 || p->nsrc == 2, "chap_conv_fwd: nsrc=%d", p->nsrc);
+    for (int i = 0; i < p->nsrc; ++i) { int r = check_src(p->src[i], "chap_conv_fwd src"); if (r) return r; }
+    CHAP_CHECK_ARG(p->combine == 0 || (p->nsrc == 1 || p->src[0].C == p->src[1].C), "chap_conv_fwd: add-combine needs equal C");
+    CHAP_CHECK_ARG(p->N > 0 && p->D > 0 && p->H > 0 && p->W > 0, "chap_conv_fwd: empty grid");
+    CHAP_CHECK_ARG(p->dims == 2 || p->dims == 3, "chap_conv_fwd: dims=%d", p->dims);
+    CHAP_CHECK_ARG(p->wpacked && p->out && p->Cout > 0, "chap_conv_fwd: null weights/out");
+    const int sd = p->dims == 3 ? p->stride : 1;
+    CHAP_CHECK_ARG(p->ID == (p->stride == 1 ? p->D : p->D * sd) && p->IH == p->H * p->stride && p->IW == p->W * p->stride,
+                   "chap_conv_fwd: input dims (%d,%d,%d) do not match grid (%d,%d,%d) stride %d", p->ID, p->IH, p->IW, p->D, p->H, p->W, p->stride);
+    if (p->out_mode == 1) CHAP_CHECK_ARG(p->out_Cn > 0 && p->out_Cn % 16 == 0 && p->Cout % p->out_Cn == 0, "chap_conv_fwd: depth-to-space needs Cn%%16==0");
+    if (!p->out_planar) CHAP_CHECK_ARG(p->out_ld % 4 == 0 && p->out_coff % 4 == 0, "chap_conv_fwd: out_ld/out_coff must be multiples of 4");
+    const int Ck = p->combine == 0 ? p->src[0].C + (p->nsrc > 1 ? p->src[1].C : 0) : p->src[0].C;
+    const int taps = p->ksize * p->ksize * (p->dims == 3 ? p->ksize : 1);
+    conv_blocking b = blocking_for(Ck, taps, p->Cout);
+    CHAP_CHECK_ARG(Ck % b.KC == 0, "chap_conv_fwd: K channels %d not a multiple of %d", Ck, b.KC);
+    const int NT = b.ntiles >= 4 ? 4 : (b.ntiles >= 2 ? 2 : 1);
+    if (p->dtype == CHAP_BF16) return chap_conv_launch_bf16(p, b.KC, NT, (hipStream_t)stream);
+    if (p->dtype == CHAP_F32) return chap_conv_launch_f32(p, b.KC, NT, (hipStream_t)stream);
+    chap_set_error("chap_conv_fwd: dtype=%d", p->dtype);
+    return CHAP_EINVAL;
+}
+
+// ---- weight packing ------------------------------------------------------------------------
+struct pack_geom { int Ck, Cn_logical, ctaps; };
+static int pack_geometry(const chap_pack_params* p, pack_geom* g) {
+    switch (p->kind) {
+        case CHAP_PACK_CONV_FWD:     g->Ck = p->Cin;  g->Cn_logical = p->Cout;           g->ctaps = p->taps; break;
+        case CHAP_PACK_CONV_DGRAD:   g->Ck = p->Cout; g->Cn_logical = p->Cin;            g->ctaps = p->taps; break;
+        case CHAP_PACK_DECONV_FWD:   g->Ck = p->Cin;  g->Cn_logical = p->taps * p->Cout; g->ctaps = 1;       break;
+        case CHAP_PACK_DECONV_DGRAD: g->Ck = p->Cout; g->Cn_logical = p->Cin;            g->ctaps = p->taps; break;
+        case CHAP_PACK_DOWN_DGRAD:   g->Ck = p->Cout; g->Cn_logical = p->taps * p->Cin;  g->ctaps = 1;       break;
+        default: chap_set_error("chap_pack: kind=%d", p->kind); return CHAP_EINVAL;
+    }
+    return CHAP_OK;
+}
+
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ out, int kind, int Cin, int Cout, int taps,
+                            int KC, int GPT, int NP, int STEPS, int nchunks, int ntiles, int Cn_logical) {
+    const long total = (long)nchunks * STEPS * ntiles * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        long r = i >> 6;
+        const int nt = (int)(r % ntiles); r /= ntiles;
+        const int step = (int)(r % STEPS);
+        const int chunk = (int)(r / STEPS);
+        const int g = lane >> 4, n16 = lane & 15;
+        const int pp = step * 4 + g;
+        const int nl = nt * 16 + n16;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = 0.f;
+            if (pp < NP && nl < Cn_logical) {
+                const int tap = pp / GPT, c = chunk * KC + (pp % GPT) * 8 + j;
+                long a;
+                switch (kind) {
+                    case CHAP_PACK_CONV_FWD:     a = ((long)nl * Cin + c) * taps + tap; break;
+                    case CHAP_PACK_CONV_DGRAD:   a = ((long)c * Cin + nl) * taps + (taps - 1 - tap); break;
+                    case CHAP_PACK_DECONV_FWD:   a = ((long)c * Cout + (nl % Cout)) * taps + (nl / Cout); break;
+                    case CHAP_PACK_DECONV_DGRAD: a = ((long)nl * Cout + c) * taps + tap; break;
+                    default:                     a = ((long)c * Cin + (nl % Cin)) * taps + (nl / Cin); break;  // DOWN_DGRAD
+                }
+                x = w[a];
+            }
+            v[j] = x;
+        }
+        st8(out + i * 8, v);
+    }
+}
+
+extern "C" size_t chap_pack_size(const chap_pack_params* p) {
+    pack_geom g;
+    if (!p || pack_geometry(p, &g)) return 0;
+    conv_blocking b = blocking_for(g.Ck, g.ctaps, g.Cn_logical);
+    return (size_t)b.nchunks * b.STEPS * b.ntiles * 64 * 8 * (p->dtype == CHAP_BF16 ? 2 : 4);
+}
+
+extern "C" int chap_pack_weights(const chap_pack_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->w && p->out, "chap_pack_weights: null argument");
+    pack_geom g;
+    int r = pack_geometry(p, &g);
+    if (r) return r;
+    CHAP_CHECK_ARG(g.Ck % 16 == 0, "chap_pack_weights: K channels %d must be a multiple of 16", g.Ck);
+    conv_blocking b = blocking_for(g.Ck, g.ctaps, g.Cn_logical);
+    CHAP_CHECK_ARG(g.Ck % b.KC == 0, "chap_pack_weights: K channels %d not a multiple of %d", g.Ck, b.KC);
+    const long total = (long)b.nchunks * b.STEPS * b.ntiles * 64;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (p->dtype == CHAP_BF16)
+        hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p->w, (bf16_t*)p->out, p->kind, p->Cin, p->Cout, p->taps,
+                           b.KC, b.GPT, b.NP, b.STEPS, b.nchunks, b.ntiles, g.Cn_logical);
+    else if (p->dtype == CHAP_F32)
+        hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p->w, (float*)p->out, p->kind, p->Cin, p->Cout, p->taps,
+                           b.KC, b.GPT, b.NP, b.STEPS, b.nchunks, b.ntiles, g.Cn_logical);
+    else { chap_set_error("chap_pack_weights: dtype=%d", p->dtype); return CHAP_EINVAL; }
+    CHAP_LAUNCH_CHECK("chap_pack_weights");
+    return CHAP_OK;
+}

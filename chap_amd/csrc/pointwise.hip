@@ -1,0 +1,588 @@
+// Element-wise / reduction kernels around the convolutions: first-layer (Cin = 1) direct conv,
+// BatchNorm finalize, lazy-activation max-pool, align_corners 2x upsample (+ adjoint), the
+// BN/activation backward pair, layout converters.  All HBM-bound: 16-byte vector accesses along
+// the channel axis, wave64 shuffle reductions, one float atomic per block and channel.
+#include "common.h"
+
+// =========================================================================================
+// First conv, Cin = 1, k3 s1 "same" (unet.py:50 with in_chns=1; vnet.py:19 with n_channels=1).
+// One thread per output pixel computes all Cout (<= 32) channels; weights + bias live in LDS.
+template <typename T, bool D3, int CO>
+__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const chap_conv_c1_params P) {
+    constexpr int KD = D3 ? 3 : 1, TAPS = KD * 9;
+    __shared__ float ws[CO * TAPS + CO];
+    __shared__ float bstat[2 * CO];
+    for (int i = threadIdx.x; i < CO * TAPS; i += 256) ws[i] = P.w[i];
+    for (int i = threadIdx.x; i < CO; i += 256) ws[CO * TAPS + i] = P.bias ? P.bias[i] : 0.f;
+    for (int i = threadIdx.x; i < 2 * CO; i += 256) bstat[i] = 0.f;
+    __syncthreads();
+    const long npix = (long)P.N * P.D * P.H * P.W;
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    const bool valid = pix < npix;
+    if (valid) {
+        const int x = (int)(pix % P.W); long r = pix / P.W;
+        const int y = (int)(r % P.H); r /= P.H;
+        const int z = (int)(r % P.D); const int n = (int)(r / P.D);
+        float in[TAPS];
+#pragma unroll
+        for (int dz = 0; dz < KD; ++dz)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int zz = z + dz - (D3 ? 1 : 0), yy = y + dy - 1, xx = x + dx - 1;
+                    const bool ib = (unsigned)zz < (unsigned)P.D && (unsigned)yy < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
+                    in[(dz * 3 + dy) * 3 + dx] = ib ? P.x[(((long)n * P.D + zz) * P.H + yy) * P.W + xx] : 0.f;
+                }
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            float a = ws[CO * TAPS + c];
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) a = fmaf(in[t], ws[c * TAPS + t], a);
+            acc[c] = a;
+        }
+        T* o = (T*)P.out + pix * CO;
+#pragma unroll
+        for (int c = 0; c < CO; c += 8) st8(o + c, acc + c);
+    }
+    if (P.stats) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const float v = valid ? acc[c] : 0.f;
+            const float s = wave_sum(v), q = wave_sum(v * v);
+            if ((threadIdx.x & 63) == 0) { atomicAdd(&bstat[c], s); atomicAdd(&bstat[CO + c], q); }
+        }
+        __syncthreads();
+        const int rep = P.stats_reps > 1 ? blockIdx.x % P.stats_reps : 0;
+        for (int i = threadIdx.x; i < 2 * CO; i += 256) atomicAdd(&P.stats[(long)rep * 2 * CO + i], bstat[i]);
+    }
+}
+
+extern "C" int chap_conv_c1_fwd(const chap_conv_c1_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->x && p->w && p->out, "chap_conv_c1_fwd: null argument");
+    CHAP_CHECK_ARG(p->Cout == 16, "chap_conv_c1_fwd: Cout=%d (only 16 built)", p->Cout);
+    CHAP_CHECK_ARG(p->dims == 2 || p->dims == 3, "chap_conv_c1_fwd: dims=%d", p->dims);
+    const long npix = (long)p->N * p->D * p->H * p->W;
+    dim3 grid((unsigned)cdiv(npix, 256));
+    hipStream_t s = (hipStream_t)stream;
+    const bool d3 = p->dims == 3, bf = p->dtype == CHAP_BF16;
+    if (bf && d3) hipLaunchKernelGGL((conv_c1_fwd_kernel<bf16_t, true, 16>), grid, dim3(256), 0, s, *p);
+    else if (bf) hipLaunchKernelGGL((conv_c1_fwd_kernel<bf16_t, false, 16>), grid, dim3(256), 0, s, *p);
+    else if (d3) hipLaunchKernelGGL((conv_c1_fwd_kernel<float, true, 16>), grid, dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL((conv_c1_fwd_kernel<float, false, 16>), grid, dim3(256), 0, s, *p);
+    CHAP_LAUNCH_CHECK("chap_conv_c1_fwd");
+    return CHAP_OK;
+}
+
+// Backward of the first conv: dx (VAT needs dL/dx), dw, db.
+//   dx[p]      = sum_{tap,c} g[p - tap + pad][c] * w[c][tap]
+//   dw[c][tap] = sum_p x[p + tap - pad] * g[p][c]      (block partials -> ws, then one reduce pass)
+template <typename T, bool D3, int CO>
+__global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const chap_conv_c1_bwd_params P, int nblocks) {
+    constexpr int KD = D3 ? 3 : 1, TAPS = KD * 9;
+    __shared__ float ws[CO * TAPS];
+    __shared__ float part[4][CO * TAPS + CO];
+    for (int i = threadIdx.x; i < CO * TAPS; i += 256) ws[i] = P.w[i];
+    __syncthreads();
+    const long npix = (long)P.N * P.D * P.H * P.W;
+    const T* g = (const T*)P.g;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // ---- dx ----
+    if (P.dx) {
+        for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)nblocks * 256) {
+            const int x = (int)(pix % P.W); long r = pix / P.W;
+            const int y = (int)(r % P.H); r /= P.H;
+            const int z = (int)(r % P.D); const int n = (int)(r / P.D);
+            float a = 0.f;
+#pragma unroll
+            for (int dz = 0; dz < KD; ++dz)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int zz = z - dz + (D3 ? 1 : 0), yy = y - dy + 1, xx = x - dx + 1;
+                        if ((unsigned)zz < (unsigned)P.D && (unsigned)yy < (unsigned)P.H && (unsigned)xx < (unsigned)P.W) {
+                            const long q = (((long)n * P.D + zz) * P.H + yy) * P.W + xx;
+                            const int tap = (dz * 3 + dy) * 3 + dx;
+#pragma unroll
+                            for (int c = 0; c < CO; c += 8) {
+                                float v[8];
+                                ld8(g + q * CO + c, v);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) a = fmaf(v[j], ws[(c + j) * TAPS + tap], a);
+                            }
+                        }
+                    }
+            P.dx[pix] = a;
+        }
+    }
+    // ---- dw / db partials: thread t handles channel c = t % CO and pixel-lane q = t / CO ----
+    if (P.dw || P.db) {
+        constexpr int PL = 256 / CO;          // pixels processed in parallel per block step
+        const int c = threadIdx.x % CO, q = threadIdx.x / CO;
+        float a[TAPS], ab = 0.f;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) a[t] = 0.f;
+        for (long pix = (long)blockIdx.x * PL + q; pix < npix; pix += (long)nblocks * PL) {
+            const int x = (int)(pix % P.W); long r = pix / P.W;
+            const int y = (int)(r % P.H); r /= P.H;
+            const int z = (int)(r % P.D); const int n = (int)(r / P.D);
+            const float gv = elem<T>::get(g[pix * CO + c]);
+            ab += gv;
+#pragma unroll
+            for (int dz = 0; dz < KD; ++dz)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int zz = z + dz - (D3 ? 1 : 0), yy = y + dy - 1, xx = x + dx - 1;
+                        const bool ib = (unsigned)zz < (unsigned)P.D && (unsigned)yy < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
+                        const float xv = ib ? P.x[(((long)n * P.D + zz) * P.H + yy) * P.W + xx] : 0.f;
+                        a[(dz * 3 + dy) * 3 + dx] = fmaf(xv, gv, a[(dz * 3 + dy) * 3 + dx]);
+                    }
+        }
+        // reduce over q (threads with equal c): lanes c, c+CO, c+2CO, ... inside a wave, then across waves via LDS
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            float v = a[t];
+            for (int o = CO; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (lane < CO) part[wave][c * TAPS + t] = v;
+        }
+        {
+            float v = ab;
+            for (int o = CO; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (lane < CO) part[wave][CO * TAPS + c] = v;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < CO * TAPS + CO; i += 256)
+            P.ws[(long)blockIdx.x * (CO * TAPS + CO) + i] = part[0][i] + part[1][i] + part[2][i] + part[3][i];
+    }
+}
+
+template <int CO>
+__global__ void conv_c1_reduce_kernel(const float* ws, int nblocks, int taps, float* dw, float* db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int tot = CO * taps + CO;
+    if (i >= tot) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += ws[(long)b * tot + i];
+    if (i < CO * taps) { if (dw) dw[i] += s; } else if (db) db[i - CO * taps] += s;
+}
+
+static int c1_bwd_blocks(const chap_conv_c1_bwd_params* p) {
+    const long npix = (long)p->N * p->D * p->H * p->W;
+    long b = (npix + 255) / 256;
+    return (int)(b < 1024 ? b : 1024);
+}
+extern "C" size_t chap_conv_c1_bwd_ws(const chap_conv_c1_bwd_params* p) {
+    const int taps = p->dims == 3 ? 27 : 9;
+    return (size_t)c1_bwd_blocks(p) * (p->Cout * taps + p->Cout) * sizeof(float);
+}
+extern "C" int chap_conv_c1_bwd(const chap_conv_c1_bwd_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->g && p->w, "chap_conv_c1_bwd: null argument");
+    CHAP_CHECK_ARG(p->Cout == 16, "chap_conv_c1_bwd: Cout=%d (only 16 built)", p->Cout);
+    CHAP_CHECK_ARG(!(p->dw || p->db) || (p->ws && p->x), "chap_conv_c1_bwd: dw/db need x and ws");
+    const int nb = c1_bwd_blocks(p);
+    hipStream_t s = (hipStream_t)stream;
+    const bool d3 = p->dims == 3, bf = p->dtype == CHAP_BF16;
+    if (bf && d3) hipLaunchKernelGGL((conv_c1_bwd_kernel<bf16_t, true, 16>), dim3(nb), dim3(256), 0, s, *p, nb);
+    else if (bf) hipLaunchKernelGGL((conv_c1_bwd_kernel<bf16_t, false, 16>), dim3(nb), dim3(256), 0, s, *p, nb);
+    else if (d3) hipLaunchKernelGGL((conv_c1_bwd_kernel<float, true, 16>), dim3(nb), dim3(256), 0, s, *p, nb);
+    else hipLaunchKernelGGL((conv_c1_bwd_kernel<float, false, 16>), dim3(nb), dim3(256), 0, s, *p, nb);
+    CHAP_LAUNCH_CHECK("chap_conv_c1_bwd");
+    if (p->dw || p->db) {
+        const int taps = d3 ? 27 : 9, tot = 16 * taps + 16;
+        hipLaunchKernelGGL((conv_c1_reduce_kernel<16>), dim3(cdiv(tot, 256)), dim3(256), 0, s, (const float*)p->ws, nb, taps, p->dw, p->db);
+        CHAP_LAUNCH_CHECK("chap_conv_c1_bwd(reduce)");
+    }
+    return CHAP_OK;
+}
+
+// =========================================================================================
+// BatchNorm finalize: batch statistics -> (scale, shift) of the lazy activation; running stats
+// follow F.batch_norm(training=True): running = (1-m)*running + m*batch, unbiased variance.
+__global__ void bn_finalize_kernel(const chap_bn_finalize_params P) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && P.num_batches_tracked && P.momentum > 0.f) *P.num_batches_tracked += 1;
+    if (c >= P.C) return;
+    float s = 0.f, q = 0.f;
+    for (int r = 0; r < P.stats_reps; ++r) { s += P.stats[(long)r * 2 * P.C + c]; q += P.stats[(long)r * 2 * P.C + P.C + c]; }
+    const float mean = s / P.count;
+    float var = q / P.count - mean * mean;
+    var = var > 0.f ? var : 0.f;
+    const float invstd = rsqrtf(var + P.eps);
+    const float sc = P.gamma[c] * invstd;
+    P.scale[c] = sc;
+    P.shift[c] = P.beta[c] - mean * sc;
+    if (P.mean) { P.mean[c] = mean; P.invstd[c] = invstd; }
+    if (P.momentum > 0.f && P.running_mean) {
+        const float unb = P.count > 1.f ? var * P.count / (P.count - 1.f) : var;
+        P.running_mean[c] = (1.f - P.momentum) * P.running_mean[c] + P.momentum * mean;
+        P.running_var[c] = (1.f - P.momentum) * P.running_var[c] + P.momentum * unb;
+    }
+}
+extern "C" int chap_bn_finalize(const chap_bn_finalize_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->stats && p->gamma && p->beta && p->scale && p->shift && p->C > 0 && p->count > 0, "chap_bn_finalize: bad argument");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(p->C, 64)), dim3(64), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_bn_finalize");
+    return CHAP_OK;
+}
+
+__global__ void bn_eval_kernel(const chap_bn_eval_params P) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= P.C) return;
+    const float sc = P.gamma[c] * rsqrtf(P.running_var[c] + P.eps);
+    P.scale[c] = sc;
+    P.shift[c] = P.beta[c] - P.running_mean[c] * sc;
+}
+extern "C" int chap_bn_eval_affine(const chap_bn_eval_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->gamma && p->beta && p->running_mean && p->running_var && p->scale && p->shift && p->C > 0, "chap_bn_eval_affine: bad argument");
+    hipLaunchKernelGGL(bn_eval_kernel, dim3(cdiv(p->C, 64)), dim3(64), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_bn_eval_affine");
+    return CHAP_OK;
+}
+
+// =========================================================================================
+// 2x2 max-pool of a lazy activation. One thread per (pooled pixel, 8 channels).
+template <typename T>
+__global__ __launch_bounds__(256) void act_pool2_kernel(const chap_pool_params P) {
+    const int C8 = P.r.C / 8, OH = P.H / 2, OW = P.W / 2;
+    const long total = (long)P.N * OH * OW * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8) * 8; long r = i / C8;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH); const int n = (int)(r / OH);
+        float best[8]; uint32_t bi[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long pix = ((long)n * P.H + 2 * oy + (k >> 1)) * P.W + 2 * ox + (k & 1);
+            float v[8];
+            src_load8<T>(P.r, n, pix, c8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (k == 0 || v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; bi[j] = k; }
+        }
+        const long op = ((long)n * OH + oy) * OW + ox;
+        st8((T*)P.out + op * P.r.C + c8, best);
+        if (P.idx) {
+            uint2 m;
+            m.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+            m.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+            *(uint2*)(P.idx + op * P.r.C + c8) = m;
+        }
+    }
+}
+extern "C" int chap_act_pool2(const chap_pool_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->r.ptr && p->out, "chap_act_pool2: null argument");
+    CHAP_CHECK_ARG(p->r.C % 8 == 0 && p->H % 2 == 0 && p->W % 2 == 0, "chap_act_pool2: C%%8, even H/W required");
+    const long total = (long)p->N * (p->H / 2) * (p->W / 2) * (p->r.C / 8);
+    const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(act_pool2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(act_pool2_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_act_pool2");
+    return CHAP_OK;
+}
+
+// =========================================================================================
+// 2x upsample, align_corners=True: src = dst * (in-1)/(out-1)  (F.interpolate bilinear/trilinear).
+__device__ __forceinline__ void ac_coord(int o, int in, int out, int& i0, int& i1, float& w1) {
+    const float sc = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+    const float f = sc * (float)o;
+    i0 = (int)f;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + 1 < in ? i0 + 1 : in - 1;
+    w1 = f - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const chap_upsample_params P) {
+    const int C8 = P.r.C / 8;
+    const int OD = P.dims == 3 ? 2 * P.D : P.D, OH = 2 * P.H, OW = 2 * P.W;
+    const long total = (long)P.N * OD * OH * OW * C8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8) * 8; long r = i / C8;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH); r /= OH;
+        const int oz = (int)(r % OD); const int n = (int)(r / OD);
+        int x0, x1, y0, y1, z0, z1; float wx, wy, wz;
+        ac_coord(ox, P.W, OW, x0, x1, wx);
+        ac_coord(oy, P.H, OH, y0, y1, wy);
+        if (P.dims == 3) ac_coord(oz, P.D, OD, z0, z1, wz); else { z0 = z1 = oz; wz = 0.f; }
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        const int nz = P.dims == 3 ? 2 : 1;
+        for (int kz = 0; kz < nz; ++kz)
+            for (int ky = 0; ky < 2; ++ky)
+                for (int kx = 0; kx < 2; ++kx) {
+                    const float w = (kz ? wz : 1.f - wz) * (ky ? wy : 1.f - wy) * (kx ? wx : 1.f - wx);
+                    const long pix = (((long)n * P.D + (kz ? z1 : z0)) * P.H + (ky ? y1 : y0)) * P.W + (kx ? x1 : x0);
+                    float v[8];
+                    src_load8<T>(P.r, n, pix, c8, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, v[j], acc[j]);
+                }
+        const long op = (((long)n * OD + oz) * OH + oy) * OW + ox;
+        st8((T*)P.out + op * P.out_ld + P.out_coff + c8, acc);
+    }
+}
+extern "C" int chap_upsample2x(const chap_upsample_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->r.ptr && p->out && p->r.C % 8 == 0, "chap_upsample2x: bad argument");
+    CHAP_CHECK_ARG(p->out_ld % 8 == 0 && p->out_coff % 8 == 0, "chap_upsample2x: out_ld/out_coff must be multiples of 8");
+    const long total = (long)p->N * (p->dims == 3 ? 2 * p->D : p->D) * 2 * p->H * 2 * p->W * (p->r.C / 8);
+    const int blocks = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(upsample2x_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_upsample2x");
+    return CHAP_OK;
+}
+
+// Adjoint: each coarse pixel gathers from the fine pixels whose stencil touches it (no atomics).
+// Along one axis, fine index o touches coarse i iff i0(o) == i or i1(o) == i; with scale
+// (in-1)/(out-1) < 1/2 only o in [2i-2, 2i+2] can qualify, so a 5-wide window per axis suffices.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const chap_upsample_bwd_params P) {
+    const int C8 = P.C / 8;
+    const int OD = P.dims == 3 ? 2 * P.D : P.D, OH = 2 * P.H, OW = 2 * P.W;
+    const long total = (long)P.N * P.D * P.H * P.W * C8;
+    const T* g = (const T*)P.g;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c8 = (int)(i % C8) * 8; long r = i / C8;
+        const int x = (int)(r % P.W); r /= P.W;
+        const int y = (int)(r % P.H); r /= P.H;
+        const int z = (int)(r % P.D); const int n = (int)(r / P.D);
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        const int zlo = P.dims == 3 ? max(0, 2 * z - 2) : z, zhi = P.dims == 3 ? min(OD - 1, 2 * z + 2) : z;
+        for (int oz = zlo; oz <= zhi; ++oz) {
+            float wz = 1.f;
+            if (P.dims == 3) {
+                int a0, a1; float w1; ac_coord(oz, P.D, OD, a0, a1, w1);
+                wz = (a0 == z ? 1.f - w1 : 0.f) + (a1 == z ? w1 : 0.f);
+                if (wz == 0.f) continue;
+            }
+            for (int oy = max(0, 2 * y - 2); oy <= min(OH - 1, 2 * y + 2); ++oy) {
+                int b0, b1; float v1; ac_coord(oy, P.H, OH, b0, b1, v1);
+                const float wy = (b0 == y ? 1.f - v1 : 0.f) + (b1 == y ? v1 : 0.f);
+                if (wy == 0.f) continue;
+                for (int ox = max(0, 2 * x - 2); ox <= min(OW - 1, 2 * x + 2); ++ox) {
+                    int c0, c1; float u1; ac_coord(ox, P.W, OW, c0, c1, u1);
+                    const float wx = (c0 == x ? 1.f - u1 : 0.f) + (c1 == x ? u1 : 0.f);
+                    if (wx == 0.f) continue;
+                    const long fp = (((long)n * OD + oz) * OH + oy) * OW + ox;
+                    float v[8];
+                    ld8(g + fp * P.g_ld + P.g_coff + c8, v);
+                    const float w = wz * wy * wx;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, v[j], acc[j]);
+                }
+            }
+        }
+        const long cp = (((long)n * P.D + z) * P.H + y) * P.W + x;
+        st8((T*)P.out + cp * P.C + c8, acc);
+    }
+}
+extern "C" int chap_upsample2x_bwd(const chap_upsample_bwd_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->g && p->out && p->C % 8 == 0 && p->g_ld % 8 == 0 && p->g_coff % 8 == 0, "chap_upsample2x_bwd: bad argument");
+    const long total = (long)p->N * p->D * p->H * p->W * (p->C / 8);
+    const int blocks = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_upsample2x_bwd");
+    return CHAP_OK;
+}
+
+// =========================================================================================
+// Backward through the lazy activation (+ pooled consumer) and training-mode BatchNorm.
+// Thread = (pixel, 8 channels); a block covers 256/C8 pixels per step, grid-stride; per-channel
+// partial sums are reduced over the block in LDS and flushed with one atomic per channel.
+template <typename T>
+__device__ __forceinline__ void act_bwd_dz(const chap_act_bwd_params& P, int n, long pix, int y, int x, int c8, float raw[8], float dz[8]) {
+    const chap_src_t& s = P.r;
+    const int C = s.C;
+    ld8((const T*)s.ptr + pix * s.ld + s.coff + c8, raw);
+    float gsum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gsum[j] = 0.f;
+    for (int k = 0; k < P.ng; ++k) {
+        float v[8];
+        ld8((const T*)P.g[k] + pix * P.g_ld[k] + P.g_coff[k] + c8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gsum[j] += v[j];
+    }
+    if (P.g_pool) {
+        const int OH = P.H / 2, OW = P.W / 2;
+        const long pp = ((long)n * OH + (y >> 1)) * OW + (x >> 1);
+        const uint32_t me = ((y & 1) << 1) | (x & 1);
+        float v[8];
+        ld8((const T*)P.g_pool + pp * C + c8, v);
+        const uint2 m = *(const uint2*)(P.pool_idx + pp * C + c8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t w = j < 4 ? m.x : m.y;
+            if (((w >> (8 * (j & 3))) & 0xff) == me) gsum[j] += v[j];
+        }
+    }
+    // a = keep*ks*cm*leaky(z), z = scale*raw+shift  ->  da/dz = keep*ks*cm*(z>0 ? 1 : slope)
+    float a[8], b[8];
+    if (s.scale) { ld8(s.scale + c8, a); ld8(s.shift + c8, b); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float z = s.scale ? fmaf(raw[j], a[j], b[j]) : raw[j];
+        float d = gsum[j];
+        if (s.act) d *= (z > 0.f ? 1.f : s.slope);
+        dz[j] = d;
+    }
+    if (s.keep) {
+        const uint2 m = *(const uint2*)(s.keep + pix * C + c8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t w = j < 4 ? m.x : m.y;
+            dz[j] = ((w >> (8 * (j & 3))) & 0xff) ? dz[j] * s.keep_scale : 0.f;
+        }
+    }
+    if (s.chan_mul) {
+        float cm[8];
+        ld8(s.chan_mul + (long)n * C + c8, cm);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dz[j] *= cm[j];
+    }
+}
+
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params P) {
+    extern __shared__ float red[];            // [2][C] block partials (reduce phase)
+    const int C = P.r.C, C8 = C / 8;
+    const long npix = (long)P.N * P.D * P.H * P.W;
+    const int c8 = (threadIdx.x % C8) * 8;
+    const int prow = threadIdx.x / C8, PPB = 256 / C8;      // C8 in {2,4,8,...,32} divides 256
+    float s0[8], s1[8], mean[8], istd[8], k0[8], k1[8], k2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    if (P.bn) {
+        ld8(P.mean + c8, mean); ld8(P.invstd + c8, istd);
+        if (APPLY) {
+            float gm[8], a0[8], a1[8];
+            ld8(P.gamma + c8, gm); ld8(P.sums + c8, a0); ld8(P.sums + C + c8, a1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { k0[j] = gm[j] * istd[j]; k1[j] = a0[j] / P.count; k2[j] = a1[j] / P.count; }
+        }
+    }
+    if (prow < PPB) {
+        for (long pix = (long)blockIdx.x * PPB + prow; pix < npix; pix += (long)gridDim.x * PPB) {
+            const int x = (int)(pix % P.W); long r = pix / P.W;
+            const int y = (int)(r % P.H); r /= P.H;
+            const int n = (int)(r / P.D);
+            float raw[8], dz[8];
+            act_bwd_dz<T>(P, n, pix, y, x, c8, raw, dz);
+            if (!APPLY) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s0[j] += dz[j]; s1[j] += dz[j] * (raw[j] - mean[j]) * istd[j]; }
+            } else {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    o[j] = P.bn ? k0[j] * (dz[j] - k1[j] - (raw[j] - mean[j]) * istd[j] * k2[j]) : dz[j];
+                st8((T*)P.gout + pix * C + c8, o);
+            }
+        }
+    }
+    if (!APPLY) {
+        for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+        __syncthreads();
+        if (prow < PPB) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { atomicAdd(&red[c8 + j], s0[j]); atomicAdd(&red[C + c8 + j], s1[j]); }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&P.sums[i], red[i]);
+    }
+}
+
+__global__ void act_bwd_param_kernel(const float* sums, float* dgamma, float* dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    if (dbeta) dbeta[c] += sums[c];
+    if (dgamma) dgamma[c] += sums[C + c];
+}
+
+static int act_bwd_check(const chap_act_bwd_params* p) {
+    CHAP_CHECK_ARG(p && p->r.ptr, "chap_act_bwd: null argument");
+    CHAP_CHECK_ARG(p->r.C % 8 == 0 && 256 % (p->r.C / 8) == 0 && p->r.C <= 2048, "chap_act_bwd: C=%d unsupported", p->r.C);
+    CHAP_CHECK_ARG(p->ng >= 0 && p->ng <= 3, "chap_act_bwd: ng=%d", p->ng);
+    CHAP_CHECK_ARG(!p->bn || (p->mean && p->invstd && p->gamma && p->sums), "chap_act_bwd: bn needs mean/invstd/gamma/sums");
+    CHAP_CHECK_ARG(!p->g_pool || (p->pool_idx && p->D == 1 && p->H % 2 == 0 && p->W % 2 == 0), "chap_act_bwd: pooled gradient needs idx and even 2D dims");
+    return CHAP_OK;
+}
+static int act_bwd_blocks(const chap_act_bwd_params* p) {
+    const long npix = (long)p->N * p->D * p->H * p->W;
+    const int ppb = 256 / (p->r.C / 8);
+    long b = (npix + ppb - 1) / ppb;
+    return (int)(b < 2048 ? b : 2048);
+}
+extern "C" int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream) {
+    int r = act_bwd_check(p); if (r) return r;
+    CHAP_CHECK_ARG(p->bn, "chap_act_bwd_reduce: only needed with bn");
+    const size_t lds = 2 * p->r.C * sizeof(float);
+    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, false>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL((act_bwd_kernel<float, false>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_act_bwd_reduce");
+    return CHAP_OK;
+}
+extern "C" int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream) {
+    int r = act_bwd_check(p); if (r) return r;
+    CHAP_CHECK_ARG(p->gout, "chap_act_bwd_apply: null gout");
+    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, true>), dim3(act_bwd_blocks(p)), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL((act_bwd_kernel<float, true>), dim3(act_bwd_blocks(p)), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_act_bwd_apply");
+    if (p->bn && (p->dgamma || p->dbeta)) {
+        hipLaunchKernelGGL(act_bwd_param_kernel, dim3(cdiv(p->r.C, 64)), dim3(64), 0, (hipStream_t)stream, (const float*)p->sums, p->dgamma, p->dbeta, p->r.C);
+        CHAP_LAUNCH_CHECK("chap_act_bwd_apply(params)");
+    }
+    return CHAP_OK;
+}
+
+// =========================================================================================
+// Layout converters at the module boundary.
+template <typename T>
+__global__ void planar_to_cl_kernel(const chap_planar_to_cl_params P) {
+    const long total = (long)P.N * P.P * P.C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % P.C); long r = i / P.C;
+        const long pp = r % P.P; const int n = (int)(r / P.P);
+        ((T*)P.out)[(n * (long)P.P + pp) * P.out_ld + P.out_coff + c] = elem<T>::put(P.in[((long)n * P.C + c) * P.P + pp]);
+    }
+}
+extern "C" int chap_planar_to_cl(const chap_planar_to_cl_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->in && p->out, "chap_planar_to_cl: null argument");
+    const long total = (long)p->N * p->P * p->C;
+    const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(planar_to_cl_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(planar_to_cl_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_planar_to_cl");
+    return CHAP_OK;
+}
+
+template <typename T>
+__global__ void cl_to_planar_kernel(const chap_cl_to_planar_params P) {
+    const int C = P.r.C;
+    const long total = (long)P.N * P.P * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pp = i % P.P; long r = i / P.P;
+        const int c = (int)(r % C); const int n = (int)(r / C);
+        P.out[i] = src_load1<T>(P.r, n, (long)n * P.P + pp, c);
+    }
+}
+extern "C" int chap_cl_to_planar(const chap_cl_to_planar_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->r.ptr && p->out, "chap_cl_to_planar: null argument");
+    const long total = (long)p->N * p->P * p->r.C;
+    const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(cl_to_planar_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(cl_to_planar_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_cl_to_planar");
+    return CHAP_OK;
+}

@@ -1,0 +1,282 @@
+/*
+ * chap_hip.h -- C ABI of libchap_hip.so: hand-written HIP kernels (gfx950 / MI355X)
+ * for the CHAP training hot path.
+ *
+ * The reference (gardnerzhou/CHAP) has no native layer: every op on its hot path is an
+ * ATen/cuDNN call made from Python.  Each entry point below therefore replaces a group of
+ * torch.nn calls; the reference lines are cited per function.  The reference-side binding
+ * is the ctypes stub shown in INTEGRATION.md (chap_amd/_lib.py is that stub).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes in POD structs, no torch types;
+ *   - the caller owns every buffer (activations, workspaces, outputs); nothing is allocated,
+ *     freed or synchronised inside a call, so calls are legal under HIP stream capture;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it asynchronously;
+ *   - return 0 on success, a negative CHAP_E* code otherwise; chap_last_error() gives the
+ *     text (thread-local);
+ *   - activations are channel-last: [N][D][H][W][C] (2D: D = 1), element type `dtype`
+ *     (CHAP_F32 or CHAP_BF16); per-channel vectors, statistics, gradients of parameters and
+ *     logits are fp32.
+ *
+ * "Lazy activation".  A BatchNorm'd conv output is stored RAW (pre-BN).  Consumers apply
+ *     a = keep * keep_scale * chan_mul[n][c] * leaky(scale[c] * raw + shift[c], slope)
+ * while loading (chap_src_t), so the normalised/activated tensor is never written to HBM.
+ */
+#ifndef CHAP_HIP_H
+#define CHAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHAP_ABI_VERSION 1
+
+enum { CHAP_F32 = 0, CHAP_BF16 = 1 };
+enum { CHAP_OK = 0, CHAP_EINVAL = -1, CHAP_EUNSUPPORTED = -2, CHAP_ELAUNCH = -3 };
+
+/* One input of a fused op: a channel-last tensor plus the transform applied on load. */
+typedef struct {
+    const void*    ptr;        /* element type = op dtype; NULL = absent                          */
+    const float*   scale;      /* [C] or NULL (identity affine)                                   */
+    const float*   shift;      /* [C]                                                             */
+    const uint8_t* keep;       /* element-wise keep mask [N][D][H][W][C] (dense) or NULL          */
+    const float*   chan_mul;   /* [N][C] per-sample channel multiplier (Dropout3d) or NULL        */
+    int32_t        C;          /* channels taken from this tensor                                 */
+    int32_t        ld;         /* pixel stride in elements (>= coff + C)                          */
+    int32_t        coff;       /* first channel inside the pixel                                  */
+    int32_t        act;        /* 0: none, 1: leaky-relu(slope) after the affine                  */
+    float          slope;      /* 0.01 LeakyReLU (unet.py:52), 0.0 ReLU (vnet.py:28)              */
+    float          keep_scale; /* 1/(1-p) for the keep mask                                       */
+} chap_src_t;
+
+/* ------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution, forward.  Replaces nn.Conv2d/Conv3d (unet.py:50,54,86,168;
+ * vnet.py:19,76,106,189), nn.ConvTranspose2d/3d (unet.py:90; vnet.py:103) and -- with packed
+ * weights of kind *_DGRAD -- their input-gradient.  Up to two inputs, concatenated
+ * (torch.cat, unet.py:97) or added (skip add, vnet.py:202).
+ *   geometry      kernel k^3 (2D: 1 x k x k), stride s, pad (k-s)/2 ... supported (k,s):
+ *                 (3,1) "same", (1,1), (2,2) down-sampling.
+ *   out_mode 1    depth-to-space: logical output channel n' = sub*Cn + c is stored at fine pixel
+ *                 2*p + sub (transposed conv k2 s2 == 1x1 conv + depth-to-space).
+ *   stats         optional per-channel sum / sum-of-squares of the fp32 result (BatchNorm batch
+ *                 statistics, F.batch_norm training=True), accumulated with float atomics into
+ *                 stats[rep][2][Cout], rep = blockIdx % stats_reps.  Caller zeroes it.
+ */
+typedef struct {
+    chap_src_t  src[2];
+    int32_t     nsrc;          /* 1 or 2                                                          */
+    int32_t     combine;       /* 0 concat channels, 1 add                                        */
+    int32_t     N, D, H, W;    /* OUTPUT grid of the GEMM (pixels = N*D*H*W)                      */
+    int32_t     ID, IH, IW;    /* input spatial dims                                              */
+    int32_t     ksize;         /* 1, 2 or 3                                                       */
+    int32_t     stride;        /* 1 or 2                                                          */
+    int32_t     dims;          /* 2 or 3 (2: kernel and stride do not extend over D)              */
+    const void* wpacked;       /* from chap_pack_weights                                          */
+    const float* bias;         /* [Cout_logical] or NULL                                          */
+    void*       out;
+    int32_t     Cout;          /* logical GEMM N (for out_mode 1: nsub*Cn)                        */
+    int32_t     out_ld;        /* pixel stride of out in elements                                 */
+    int32_t     out_coff;
+    int32_t     out_mode;      /* 0 same grid, 1 depth-to-space (fine grid = 2x in H,W and D if dims==3) */
+    int32_t     out_Cn;        /* channels per sub-position for out_mode 1                        */
+    int32_t     out_planar;    /* 1: write fp32 [N][Cout][D][H][W] (logits, NCHW) instead         */
+    int32_t     out_f32;       /* 1: out element type is fp32 regardless of dtype                 */
+    float*      stats;         /* [stats_reps][2][Cout] or NULL                                   */
+    int32_t     stats_reps;
+    int32_t     dtype;
+} chap_conv_params;
+
+int chap_conv_fwd(const chap_conv_params* p, void* stream);
+
+/* Weight packing for chap_conv_fwd.  Reads the checkpoint-layout fp32 parameter
+ * (OIHW / OIDHW for conv, [Cin][Cout][k..] for transposed conv) and writes the MFMA fragment
+ * order consumed by the kernel. */
+enum {
+    CHAP_PACK_CONV_FWD     = 0,  /* conv weight  [Co][Ci][taps]      -> forward                   */
+    CHAP_PACK_CONV_DGRAD   = 1,  /* conv weight, k3 s1: flipped taps, Ci<->Co -> input gradient   */
+    CHAP_PACK_DECONV_FWD   = 2,  /* deconv weight [Ci][Co][sub]      -> 1x1 conv + depth-to-space */
+    CHAP_PACK_DECONV_DGRAD = 3,  /* deconv weight -> k2 s2 conv of the output gradient            */
+    CHAP_PACK_DOWN_DGRAD   = 4   /* k2 s2 conv weight [Co][Ci][sub]  -> 1x1 conv + depth-to-space */
+};
+typedef struct {
+    const float* w;            /* parameter, checkpoint layout                                    */
+    void*        out;          /* packed, element type dtype                                      */
+    int32_t      kind;
+    int32_t      Cin, Cout;    /* of the PARAMETER (nn.Module meaning)                            */
+    int32_t      taps;         /* k^2 or k^3 (sub-positions for k2 s2)                            */
+    int32_t      dtype;
+} chap_pack_params;
+size_t chap_pack_size(const chap_pack_params* p);   /* bytes of `out` */
+int    chap_pack_weights(const chap_pack_params* p, void* stream);
+
+/* First layer, Cin == 1 (encoder.in_conv / block_one first conv): direct VALU conv k3 s1.
+ * x is fp32 [N][D][H][W] (C=1: NCHW == NHWC).  Also its input gradient (VAT needs dL/dx)
+ * and weight gradient. */
+typedef struct {
+    const float* x;  const float* w;  const float* bias;  /* w: [Cout][1][taps] fp32 */
+    void* out;  float* stats;  int32_t stats_reps;
+    int32_t N, D, H, W, dims, Cout, dtype;
+} chap_conv_c1_params;
+int chap_conv_c1_fwd(const chap_conv_c1_params* p, void* stream);
+
+typedef struct {
+    const void* g;             /* gradient wrt the raw conv output [..][Cout], dtype              */
+    const float* w;            /* [Cout][1][taps]                                                 */
+    const float* x;            /* layer input (for wgrad)                                         */
+    float* dx;                 /* [N][D][H][W] fp32 or NULL                                       */
+    float* dw;                 /* [Cout][taps] fp32, accumulated (+=) or NULL                     */
+    float* db;                 /* [Cout] accumulated or NULL                                      */
+    float* ws;                 /* workspace, chap_conv_c1_bwd_ws() bytes                          */
+    int32_t N, D, H, W, dims, Cout, dtype;
+} chap_conv_c1_bwd_params;
+size_t chap_conv_c1_bwd_ws(const chap_conv_c1_bwd_params* p);
+int    chap_conv_c1_bwd(const chap_conv_c1_bwd_params* p, void* stream);
+
+/* Weight gradient of chap_conv_fwd geometries:
+ *   dW[tap][kc][kn] = sum_p A[s*p + tap - pad][kc] * B[p][kn]
+ * A = "strided" operand (halo-tiled; the layer input for conv, the fine-grid output gradient
+ * for transposed conv), B = the operand on the GEMM grid.  Both may be lazy activations.
+ * Partials are written per pixel-split to `ws` and reduced deterministically (no atomics) into
+ * dw (+=) using element strides so the result lands in checkpoint layout.  Also db (+= sum_p B)
+ * when requested (valid when B is the output gradient). */
+typedef struct {
+    chap_src_t  a[2];          /* strided operand, up to two concatenated/added sources           */
+    int32_t     na;  int32_t combine;
+    chap_src_t  b;
+    int32_t     N, D, H, W;    /* GEMM grid (B's pixels)                                          */
+    int32_t     ID, IH, IW;    /* A's spatial dims                                                */
+    int32_t     ksize, stride, dims;
+    float*      dw;            /* accumulated: dw[tap*s_tap + kc*s_kc + kn*s_kn] += ...           */
+    int64_t     s_tap, s_kc, s_kn;
+    int32_t     flip;          /* unused for forward-geometry wgrad; reserved                     */
+    float*      db;            /* [Cb] += or NULL                                                 */
+    void*       ws;  size_t ws_bytes;
+    int32_t     dtype;
+} chap_wgrad_params;
+size_t chap_wgrad_ws(const chap_wgrad_params* p);
+int    chap_wgrad(const chap_wgrad_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm pieces (nn.BatchNorm2d/3d, unet.py:51,55; vnet.py:21,80,110).                    */
+typedef struct {
+    const float* stats;  int32_t stats_reps;   /* from chap_conv_fwd                               */
+    const float* gamma;  const float* beta;    /* BN weight / bias                                 */
+    float* running_mean; float* running_var;   /* updated in place when momentum > 0               */
+    int64_t* num_batches_tracked;              /* +1 when momentum > 0 (may be NULL)               */
+    float* scale; float* shift;                /* out: affine for the lazy activation              */
+    float* mean;  float* invstd;               /* out: saved for backward                          */
+    int32_t C;  float count;  float eps;  float momentum;
+} chap_bn_finalize_params;
+int chap_bn_finalize(const chap_bn_finalize_params* p, void* stream);
+
+typedef struct {                                /* eval mode: affine from running statistics        */
+    const float* gamma; const float* beta; const float* running_mean; const float* running_var;
+    float* scale; float* shift; int32_t C; float eps;
+} chap_bn_eval_params;
+int chap_bn_eval_affine(const chap_bn_eval_params* p, void* stream);
+
+/* Backward through  a = keep*ks*cm*leaky(scale*r+shift)  [followed by optional 2x2 max-pool
+ * routing] and training-mode BatchNorm, for one stored raw tensor r.
+ *   phase 1 (reduce): dz = (sum of incoming dact grads) * da/dz;  sums[0][c] = sum dz,
+ *                     sums[1][c] = sum dz * rhat              (rhat = (r-mean)*invstd)
+ *   phase 2 (apply):  g = gamma*invstd*(dz - sums0/cnt - rhat*sums1/cnt)  -> gout (dtype)
+ *                     dgamma += sums1, dbeta += sums0
+ * Incoming gradients: up to 3 same-grid tensors (ptr, ld, coff) and one half-resolution pooled
+ * gradient routed through the saved arg-max index. With bn == 0 (no BatchNorm after the conv)
+ * phase 2 writes g = dz and no sums are needed. */
+typedef struct {
+    const void* g[3];  int32_t g_ld[3];  int32_t g_coff[3];  int32_t ng;
+    const void* g_pool; const uint8_t* pool_idx;     /* [N][H/2][W/2][C] each, or NULL           */
+    chap_src_t  r;                                   /* the raw tensor + its forward transform    */
+    const float* mean; const float* invstd; const float* gamma;
+    float* sums;            /* [2][C] workspace, zeroed by the caller                             */
+    void*  gout;            /* [pixels][C] dtype                                                  */
+    float* dgamma; float* dbeta;                     /* accumulated (+=)                          */
+    int32_t N, D, H, W;  int32_t bn;  float count;  int32_t dtype;
+} chap_act_bwd_params;
+int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream);
+int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream);
+
+/* nn.MaxPool2d(2) of a lazy activation (unet.py:69): out [N][H/2][W/2][C] + arg-max idx. */
+typedef struct { chap_src_t r; void* out; uint8_t* idx; int32_t N, H, W, dtype; } chap_pool_params;
+int chap_act_pool2(const chap_pool_params* p, void* stream);
+
+/* nn.Upsample(scale_factor=2, bilinear/trilinear, align_corners=True) of a (lazy) tensor
+ * (unet.py:87, vnet.py:105) and its adjoint. dims==2: D untouched. */
+typedef struct {
+    chap_src_t r;  void* out; int32_t out_ld, out_coff;
+    int32_t N, D, H, W;  /* INPUT dims */  int32_t dims, dtype;
+} chap_upsample_params;
+int chap_upsample2x(const chap_upsample_params* p, void* stream);
+typedef struct {
+    const void* g; int32_t g_ld, g_coff;   /* fine-grid gradient                                  */
+    void* out;                               /* coarse [..][C] dtype                                */
+    int32_t N, D, H, W, C, dims, dtype;     /* INPUT (coarse) dims                                 */
+} chap_upsample_bwd_params;
+int chap_upsample2x_bwd(const chap_upsample_bwd_params* p, void* stream);
+
+/* Layout / dtype helpers at the module boundary. */
+typedef struct { const float* in; void* out; int32_t N, C, P, out_ld, out_coff, dtype; } chap_planar_to_cl_params;
+int chap_planar_to_cl(const chap_planar_to_cl_params* p, void* stream);  /* fp32 [N][C][P] -> dtype [N][P][C] */
+typedef struct { chap_src_t r; float* out; int32_t N, P; int32_t dtype; } chap_cl_to_planar_params;
+int chap_cl_to_planar(const chap_cl_to_planar_params* p, void* stream);  /* (lazy) [N][P][C] -> fp32 [N][C][P] */
+
+/* ------------------------------------------------------------------------------------------
+ * Segmentation losses on fp32 planar logits [N][C][P]  (train_ours_2D.py:198-216, 319-325). */
+typedef struct {
+    const float* logits;        /* [N][C][P]                                                       */
+    const int64_t* target_a;    /* [N][P] labels under mask                                        */
+    const int64_t* target_b;    /* [N][P] labels under (1-mask)                                    */
+    const int64_t* mask;        /* [N][P] in {0,1}                                                 */
+    float w_a, w_b;             /* image_weight, patch_weight                                      */
+    float* acc;                 /* [2][1 + 3*C + 1] fp32 workspace, zeroed: ce, per-class i/p2/t2, msum */
+    float* loss;                /* [3]: loss_a, loss_b, total   (mix_loss return triple)           */
+    float* dlogits;             /* [N][C][P] or NULL: d(total*gscale)/dlogits, accumulated (+=) if accumulate */
+    float gscale; int32_t accumulate;
+    int32_t N, C, P; float smooth;
+} chap_mix_loss_params;
+int chap_mix_loss_fwd(const chap_mix_loss_params* p, void* stream);
+int chap_mix_loss_bwd(const chap_mix_loss_params* p, void* stream);
+
+typedef struct {               /* pass-A block: softmax, argmax, cross CE "knowledge"             */
+    const float* logits1; const float* logits2;   /* [N][C][P]                                     */
+    float* soft1; float* soft2;                    /* [N][C][P] or NULL                            */
+    int64_t* arg1; int64_t* arg2;                  /* [N][P]                                       */
+    float* knowledge;                              /* [N][P]                                       */
+    int32_t N, C, P;
+} chap_pseudo_params;
+int chap_pseudo_block(const chap_pseudo_params* p, void* stream);
+
+typedef struct {               /* KL(target || softmax(logits)) summed over both heads, / (N*P)  */
+    const float* logits[2]; const float* target[2];
+    float* loss;  float* dlogits[2];  /* loss += ; dlogits may be NULL                            */
+    float gscale; int32_t N, C, P;
+} chap_kl_params;
+int chap_kl_fwd_bwd(const chap_kl_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VAT perturbation helpers (per-sample L2 normalise, masked axpy, sign step).               */
+typedef struct { const float* in; float* out; int32_t N, P; float eps; } chap_l2norm_params;
+int chap_l2_normalize(const chap_l2norm_params* p, void* stream);   /* out[n] = in[n]/(||in[n]||+eps) */
+typedef struct { const float* x; const float* d; const float* mask; float* out; float alpha; int32_t sign; int64_t n; } chap_axpy_params;
+int chap_perturb(const chap_axpy_params* p, void* stream);          /* out = x + alpha*mask*(sign? sgn(d): d) */
+typedef struct { float* out; uint64_t seed; int64_t n; float lo, hi; } chap_rand_params;
+int chap_rand_uniform(const chap_rand_params* p, void* stream);
+typedef struct { uint8_t* keep; uint64_t seed; int64_t n; float p; } chap_keepmask_params;
+int chap_keep_mask(const chap_keepmask_params* p, void* stream);
+
+/* Fused SGD(momentum, weight decay) over a flat fp32 parameter buffer (train_ours_2D.py:278,383).
+ * lr is read from device memory so a captured graph can be replayed with a new value. */
+typedef struct { float* param; float* grad; float* mom; const float* lr; float momentum, weight_decay, grad_scale; int64_t n; int32_t first; } chap_sgd_params;
+int chap_sgd_step(const chap_sgd_params* p, void* stream);
+
+const char* chap_last_error(void);
+int chap_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,284 @@
+"""Per-kernel parity: each C-ABI entry point against a plain PyTorch fp32 CPU computation of the
+same op (floating-point kernels; tolerance stated per test).  Needs a GPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from chap_amd import _lib as L
+from chap_amd import ops
+
+DEV = "cuda"
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2.5e-2}
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def cl(x, dtype):
+    """NC(D)HW cpu fp32 -> [N,D,H,W,C] device tensor of dtype."""
+    if x.dim() == 4:
+        x = x.unsqueeze(2)
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(DEV, dtype)
+
+
+def uncl(t):
+    """[N,D,H,W,C] device -> NCDHW cpu fp32."""
+    return t.float().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def rq(x, dtype):
+    """round-trip through the storage dtype so the reference sees the same inputs."""
+    return x.to(dtype).float()
+
+
+def lazy_ref(x, scale, shift, slope, keep, ks):
+    """reference for the lazy-activation transform on an NC... cpu tensor."""
+    sh = [1, -1] + [1] * (x.dim() - 2)
+    y = x * scale.view(sh) + shift.view(sh)
+    y = torch.where(y > 0, y, y * slope)
+    if keep is not None:
+        y = y * keep * ks
+    return y
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,hw", [(16, 16, (20, 24)), (32, 64, (16, 16)), (64, 32, (9, 17)), (128, 128, (8, 16))])
+def test_conv3x3_2d_plain(dtype, cin, cout, hw):
+    g = torch.Generator().manual_seed(1)
+    N, (H, W) = 2, hw
+    x = rq(torch.randn(N, cin, H, W, generator=g), dtype)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, rq(w, dtype), b, padding=1)
+    xd = cl(x, dtype)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, cin, cout, 9)
+    out = torch.empty(N, 1, H, W, cout, device=DEV, dtype=dtype)
+    stats = torch.zeros(2, 2, cout, device=DEV)
+    ops.conv_fwd([ops.Lazy(xd)], wp, b.to(DEV), cout, out, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2,
+                 stats=stats, stats_reps=2)
+    torch.cuda.synchronize()
+    assert relerr(uncl(out).squeeze(2), ref) < TOL[dtype]
+    s = stats.sum(0).cpu()
+    assert relerr(s[0], ref.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
+    assert relerr(s[1], (ref * ref).sum((0, 2, 3))) < 1e-3 + TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3x3_concat_lazy_sources(dtype):
+    """two concatenated sources, each with BN-affine + LeakyReLU on load, one with a dropout keep mask."""
+    g = torch.Generator().manual_seed(2)
+    N, H, W, c0, c1, cout = 2, 12, 20, 16, 16, 32
+    x0 = rq(torch.randn(N, c0, H, W, generator=g), dtype)
+    x1 = rq(torch.randn(N, c1, H, W, generator=g), dtype)
+    sc0, sh0 = torch.rand(c0, generator=g) + 0.5, torch.randn(c0, generator=g) * 0.2
+    sc1, sh1 = torch.rand(c1, generator=g) + 0.5, torch.randn(c1, generator=g) * 0.2
+    keep = (torch.rand(N, c0, H, W, generator=g) > 0.3).float()
+    w = torch.randn(cout, c0 + c1, 3, 3, generator=g) / ((c0 + c1) * 9) ** 0.5
+    a0 = lazy_ref(x0, sc0, sh0, 0.01, keep, 1 / 0.7)
+    a1 = lazy_ref(x1, sc1, sh1, 0.01, None, 1.0)
+    ref = F.conv2d(torch.cat([rq(a0, dtype), rq(a1, dtype)], 1), rq(w, dtype), None, padding=1)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, c0 + c1, cout, 9)
+    out = torch.empty(N, 1, H, W, cout, device=DEV, dtype=dtype)
+    s0 = ops.Lazy(cl(x0, dtype), sc0.to(DEV), sh0.to(DEV), True, 0.01, keep=cl(keep, torch.uint8), keep_scale=1 / 0.7)
+    s1 = ops.Lazy(cl(x1, dtype), sc1.to(DEV), sh1.to(DEV), True, 0.01)
+    ops.conv_fwd([s0, s1], wp, None, cout, out, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2)
+    torch.cuda.synchronize()
+    assert relerr(uncl(out).squeeze(2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv1x1_and_planar_head(dtype):
+    g = torch.Generator().manual_seed(3)
+    N, H, W = 2, 10, 18
+    x = rq(torch.randn(N, 64, H, W, generator=g), dtype)
+    w = torch.randn(32, 64, 1, 1, generator=g) / 8
+    b = torch.randn(32, generator=g)
+    ref = F.conv2d(x, rq(w, dtype), b)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, 64, 32, 1)
+    out = torch.empty(N, 1, H, W, 32, device=DEV, dtype=dtype)
+    ops.conv_fwd([ops.Lazy(cl(x, dtype))], wp, b.to(DEV), 32, out, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=1, stride=1, dims=2)
+    assert relerr(uncl(out).squeeze(2), ref) < TOL[dtype]
+    # 3x3 head 16 -> 4, fp32 planar (NCHW) logits
+    x = rq(torch.randn(N, 16, H, W, generator=g), dtype)
+    w = torch.randn(4, 16, 3, 3, generator=g) / 12
+    b = torch.randn(4, generator=g)
+    ref = F.conv2d(x, rq(w, dtype), b, padding=1)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, 16, 4, 9)
+    out = torch.empty(N, 4, H, W, device=DEV, dtype=torch.float32)
+    ops.conv_fwd([ops.Lazy(cl(x, dtype))], wp, b.to(DEV), 4, out, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2,
+                 out_planar=True, out_f32=True)
+    assert relerr(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deconv_k2s2_2d_and_dgrads(dtype):
+    g = torch.Generator().manual_seed(4)
+    N, H, W, cin, cout = 2, 6, 10, 64, 32
+    x = rq(torch.randn(N, cin, H, W, generator=g), dtype)
+    w = torch.randn(cin, cout, 2, 2, generator=g) / 8
+    b = torch.randn(cout, generator=g)
+    ref = F.conv_transpose2d(x, rq(w, dtype), b, stride=2)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_DECONV_FWD, dtype, cin, cout, 4)
+    # write into the upper half of a concat buffer (ld = 2*cout) to exercise out_ld/out_coff
+    out = torch.zeros(N, 1, 2 * H, 2 * W, 2 * cout, device=DEV, dtype=dtype)
+    ops.conv_fwd([ops.Lazy(cl(x, dtype))], wp, b.to(DEV), 4 * cout, out, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=1, stride=1, dims=2,
+                 out_mode=1, out_cn=cout, out_coff=cout)
+    assert relerr(uncl(out[..., cout:]).squeeze(2), ref) < TOL[dtype]
+    assert out[..., :cout].abs().max().item() == 0
+    # deconv input-gradient: d_in = conv k2 s2 of the output gradient
+    gy = rq(torch.randn(N, cout, 2 * H, 2 * W, generator=g), dtype)
+    ref_dx = F.conv2d(gy, rq(w, dtype), None, stride=2)
+    wpd = ops.pack_weights(w.to(DEV), L.PACK_DECONV_DGRAD, dtype, cin, cout, 4)
+    dx = torch.empty(N, 1, H, W, cin, device=DEV, dtype=dtype)
+    ops.conv_fwd([ops.Lazy(cl(gy, dtype))], wpd, None, cin, dx, grid=(N, 1, H, W), in_dims=(1, 2 * H, 2 * W), ksize=2, stride=2, dims=2)
+    assert relerr(uncl(dx).squeeze(2), ref_dx) < TOL[dtype]
+    # conv3x3 input-gradient via flipped/transposed packing
+    wc = torch.randn(cout, cin, 3, 3, generator=g) / 24
+    gy = rq(torch.randn(N, cout, H, W, generator=g), dtype)
+    ref_dx = F.conv_transpose2d(gy, rq(wc, dtype), None, padding=1)
+    wpd = ops.pack_weights(wc.to(DEV), L.PACK_CONV_DGRAD, dtype, cin, cout, 9)
+    dx = torch.empty(N, 1, H, W, cin, device=DEV, dtype=dtype)
+    ops.conv_fwd([ops.Lazy(cl(gy, dtype))], wpd, None, cin, dx, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2)
+    assert relerr(uncl(dx).squeeze(2), ref_dx) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv3d_family(dtype):
+    g = torch.Generator().manual_seed(5)
+    N, D, H, W = 1, 6, 10, 12
+    # 3^3 conv with add-combined lazy sources (V-Net skip add, vnet.py:202)
+    c = 32
+    x0 = rq(torch.randn(N, c, D, H, W, generator=g), dtype)
+    x1 = rq(torch.randn(N, c, D, H, W, generator=g), dtype)
+    sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    cm = (torch.rand(N, c, generator=g) > 0.5).float() * 2.0
+    w = torch.randn(16, c, 3, 3, 3, generator=g) / (c * 27) ** 0.5
+    a = lazy_ref(x0, sc, sh, 0.0, None, 1.0) * cm.view(N, c, 1, 1, 1) + x1
+    ref = F.conv3d(rq(a, dtype), rq(w, dtype), None, padding=1)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, c, 16, 27)
+    out = torch.empty(N, D, H, W, 16, device=DEV, dtype=dtype)
+    s0 = ops.Lazy(cl(x0, dtype), sc.to(DEV), sh.to(DEV), True, 0.0, chan_mul=cm.to(DEV))
+    ops.conv_fwd([s0, ops.Lazy(cl(x1, dtype))], wp, None, 16, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=3, combine=1)
+    assert relerr(uncl(out), ref) < 2 * TOL[dtype]
+    # k2 s2 down conv 16 -> 32
+    x = rq(torch.randn(N, 16, D, H, W, generator=g), dtype)
+    w = torch.randn(32, 16, 2, 2, 2, generator=g) / 11
+    b = torch.randn(32, generator=g)
+    ref = F.conv3d(x, rq(w, dtype), b, stride=2)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, 16, 32, 8)
+    out = torch.empty(N, D // 2, H // 2, W // 2, 32, device=DEV, dtype=dtype)
+    ops.conv_fwd([ops.Lazy(cl(x, dtype))], wp, b.to(DEV), 32, out, grid=(N, D // 2, H // 2, W // 2), in_dims=(D, H, W), ksize=2, stride=2, dims=3)
+    assert relerr(uncl(out), ref) < TOL[dtype]
+    # its input gradient (1x1 conv + depth-to-space)
+    gy = rq(torch.randn(N, 32, D // 2, H // 2, W // 2, generator=g), dtype)
+    ref_dx = F.conv_transpose3d(gy, rq(w, dtype), None, stride=2)
+    wpd = ops.pack_weights(w.to(DEV), L.PACK_DOWN_DGRAD, dtype, 16, 32, 8)
+    dx = torch.empty(N, D, H, W, 16, device=DEV, dtype=dtype)
+    ops.conv_fwd([ops.Lazy(cl(gy, dtype))], wpd, None, 8 * 16, dx, grid=(N, D // 2, H // 2, W // 2), in_dims=(D // 2, H // 2, W // 2),
+                 ksize=1, stride=1, dims=3, out_mode=1, out_cn=16)
+    assert relerr(uncl(dx), ref_dx) < TOL[dtype]
+    # transposed conv 3D 64 -> 32 with BN statistics per real channel
+    x = rq(torch.randn(N, 64, 3, 5, 6, generator=g), dtype)
+    w = torch.randn(64, 32, 2, 2, 2, generator=g) / 8
+    b = torch.randn(32, generator=g)
+    ref = F.conv_transpose3d(x, rq(w, dtype), b, stride=2)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_DECONV_FWD, dtype, 64, 32, 8)
+    out = torch.empty(N, 6, 10, 12, 32, device=DEV, dtype=dtype)
+    stats = torch.zeros(1, 2, 32, device=DEV)
+    ops.conv_fwd([ops.Lazy(cl(x, dtype))], wp, b.to(DEV), 8 * 32, out, grid=(N, 3, 5, 6), in_dims=(3, 5, 6), ksize=1, stride=1, dims=3,
+                 out_mode=1, out_cn=32, stats=stats)
+    assert relerr(uncl(out), ref) < TOL[dtype]
+    assert relerr(stats[0, 0].cpu(), ref.sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
+    assert relerr(stats[0, 1].cpu(), (ref * ref).sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
+    # 1x1x1 head 16 -> 2, planar fp32
+    x = rq(torch.randn(N, 16, D, H, W, generator=g), dtype)
+    w = torch.randn(2, 16, 1, 1, 1, generator=g) / 4
+    b = torch.randn(2, generator=g)
+    ref = F.conv3d(x, rq(w, dtype), b)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, 16, 2, 1)
+    out = torch.empty(N, 2, D, H, W, device=DEV)
+    ops.conv_fwd([ops.Lazy(cl(x, dtype))], wp, b.to(DEV), 2, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=1, stride=1, dims=3,
+                 out_planar=True, out_f32=True)
+    assert relerr(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dims", [2, 3])
+def test_first_conv_c1(dtype, dims):
+    g = torch.Generator().manual_seed(6)
+    shape = (2, 1, 20, 28) if dims == 2 else (1, 6, 10, 12)
+    x = torch.randn(shape, generator=g)
+    taps = 9 if dims == 2 else 27
+    w = torch.randn(16, 1, *([3] * dims), generator=g) / taps ** 0.5
+    b = torch.randn(16, generator=g)
+    xin = x[:, 0].unsqueeze(1) if dims == 2 else x.unsqueeze(1)
+    ref = (F.conv2d if dims == 2 else F.conv3d)(xin, w, b, padding=1)
+    xd = x.to(DEV)
+    out = torch.empty(*xd.shape, 16, device=DEV, dtype=dtype)
+    stats = torch.zeros(4, 2, 16, device=DEV)
+    ops.conv_c1_fwd(xd, w.to(DEV), b.to(DEV), out, dims=dims, stats=stats, stats_reps=4)
+    got = uncl(out)
+    if dims == 2:
+        got = got.squeeze(2)
+    assert relerr(got, ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert relerr(stats.sum(0)[0].cpu(), ref.sum([0] + list(range(2, ref.dim())))) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pool_upsample_bnfinalize(dtype):
+    g = torch.Generator().manual_seed(7)
+    N, C, H, W = 2, 32, 12, 16
+    x = rq(torch.randn(N, C, H, W, generator=g), dtype)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    a = lazy_ref(x, sc, sh, 0.01, None, 1.0)
+    ref = F.max_pool2d(a, 2)
+    lz = ops.Lazy(cl(x, dtype), sc.to(DEV), sh.to(DEV), True, 0.01)
+    out = torch.empty(N, 1, H // 2, W // 2, C, device=DEV, dtype=dtype)
+    idx = torch.empty(N, 1, H // 2, W // 2, C, device=DEV, dtype=torch.uint8)
+    ops.act_pool2(lz, out, idx)
+    assert relerr(uncl(out).squeeze(2), ref) < (1e-6 if dtype == torch.float32 else 1e-2)
+    # bilinear x2 align_corners=True of a plain tensor into a concat slot
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    up = torch.zeros(N, 1, 2 * H, 2 * W, 2 * C, device=DEV, dtype=dtype)
+    ops.upsample2x(ops.Lazy(cl(x, dtype)), up, dims=2, out_coff=C)
+    assert relerr(uncl(up[..., C:]).squeeze(2), ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+    # adjoint
+    gy = rq(torch.randn(N, C, 2 * H, 2 * W, generator=g), dtype)
+    xr = x.clone().requires_grad_(True)
+    F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True).backward(gy)
+    gcat = torch.zeros(N, 1, 2 * H, 2 * W, 2 * C, device=DEV, dtype=dtype)
+    gcat[..., C:] = cl(gy, dtype)
+    dxo = torch.empty(N, 1, H, W, C, device=DEV, dtype=dtype)
+    ops.upsample2x_bwd(gcat, C, C, dxo, dims=2)
+    assert relerr(uncl(dxo).squeeze(2), xr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+    # trilinear of a lazy ReLU'd tensor
+    x3 = rq(torch.randn(1, 16, 3, 5, 6, generator=g), dtype)
+    sc3, sh3 = torch.rand(16, generator=g) + 0.5, torch.randn(16, generator=g) * 0.2
+    ref = F.interpolate(lazy_ref(x3, sc3, sh3, 0.0, None, 1.0), scale_factor=2, mode="trilinear", align_corners=True)
+    up = torch.empty(1, 6, 10, 12, 16, device=DEV, dtype=dtype)
+    ops.upsample2x(ops.Lazy(cl(x3, dtype), sc3.to(DEV), sh3.to(DEV), True, 0.0), up, dims=3)
+    assert relerr(uncl(up), ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+    gy = rq(torch.randn(1, 16, 6, 10, 12, generator=g), dtype)
+    xr = x3.clone().requires_grad_(True)
+    F.interpolate(xr, scale_factor=2, mode="trilinear", align_corners=True).backward(gy)
+    dxo = torch.empty(1, 3, 5, 6, 16, device=DEV, dtype=dtype)
+    ops.upsample2x_bwd(cl(gy, dtype), 0, 16, dxo, dims=3)
+    assert relerr(uncl(dxo), xr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+    # BN finalize vs F.batch_norm bookkeeping
+    y = torch.randn(4, C, 6, 6, generator=g) * 2 + 1
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.batch_norm(y, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    stats = torch.stack([y.sum((0, 2, 3)), (y * y).sum((0, 2, 3))]).unsqueeze(0).to(DEV).contiguous()
+    scale, shift = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    rmd, rvd, nbt = rm.to(DEV), rv.to(DEV), torch.zeros((), dtype=torch.long, device=DEV)
+    ops.bn_finalize(stats, 1, gamma.to(DEV), beta.to(DEV), rmd, rvd, nbt, 4 * 36, 1e-5, 0.1, scale, shift, mean, invstd)
+    got = y * scale.cpu().view(1, C, 1, 1) + shift.cpu().view(1, C, 1, 1)
+    assert relerr(got, ref) < 1e-5
+    assert relerr(rmd, rm_ref) < 1e-5 and relerr(rvd, rv_ref) < 1e-5 and int(nbt) == 1
