@@ -49,7 +49,7 @@ class WgradParams(C.Structure):
     _fields_ = [("a", Src * 2), ("na", _i32), ("combine", _i32), ("b", Src),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("ID", _i32), ("IH", _i32), ("IW", _i32),
                 ("ksize", _i32), ("stride", _i32), ("dims", _i32),
-                ("dw", _vp), ("s_tap", _i64), ("s_kc", _i64), ("s_kn", _i64), ("flip", _i32),
+                ("dw", _vp), ("s_tap", _i64), ("s_kc", _i64), ("s_kn", _i64), ("kc_valid", _i32), ("kn_valid", _i32),
                 ("db", _vp), ("ws", _vp), ("ws_bytes", _sz), ("dtype", _i32)]
 
 
@@ -108,7 +108,7 @@ class PseudoParams(C.Structure):
 
 class KlParams(C.Structure):
     _fields_ = [("logits", _vp * 2), ("target", _vp * 2), ("loss", _vp), ("dlogits", _vp * 2),
-                ("gscale", _f32), ("N", _i32), ("C", _i32), ("P", _i32)]
+                ("gscale", _f32), ("gscale_dev", _vp), ("N", _i32), ("C", _i32), ("P", _i32)]
 
 
 class L2NormParams(C.Structure):
@@ -120,16 +120,37 @@ class AxpyParams(C.Structure):
 
 
 class RandParams(C.Structure):
-    _fields_ = [("out", _vp), ("seed", C.c_uint64), ("n", _i64), ("lo", _f32), ("hi", _f32)]
+    _fields_ = [("out", _vp), ("seed", C.c_uint64), ("seed_dev", _vp), ("n", _i64), ("lo", _f32), ("hi", _f32)]
 
 
 class KeepMaskParams(C.Structure):
-    _fields_ = [("keep", _vp), ("seed", C.c_uint64), ("n", _i64), ("p", _f32)]
+    _fields_ = [("keep", _vp), ("seed", C.c_uint64), ("seed_dev", _vp), ("n", _i64), ("p", _f32)]
+
+
+class ChanMaskParams(C.Structure):
+    _fields_ = [("mul", _vp), ("seed", C.c_uint64), ("seed_dev", _vp), ("n", _i64), ("p", _f32)]
+
+
+class BoxMixParams(C.Structure):
+    _fields_ = [("a", _vp), ("b", _vp), ("out", _vp), ("box", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("is_i64", _i32)]
+
+
+class BoxMaskParams(C.Structure):
+    _fields_ = [("mask", _vp), ("box", _vp), ("N", _i32), ("H", _i32), ("W", _i32)]
+
+
+class LccParams(C.Structure):
+    _fields_ = [("labels", _vp), ("out", _vp), ("ws", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("num_classes", _i32)]
+
+
+class DiffMaskParams(C.Structure):
+    _fields_ = [("p1", _vp), ("p2", _vp), ("knowledge", _vp), ("out", _vp), ("pooled_ws", _vp),
+                ("N", _i32), ("H", _i32), ("W", _i32), ("scale", _i32), ("topk", _f32)]
 
 
 class SgdParams(C.Structure):
     _fields_ = [("param", _vp), ("grad", _vp), ("mom", _vp), ("lr", _vp), ("momentum", _f32), ("weight_decay", _f32),
-                ("grad_scale", _f32), ("n", _i64), ("first", _i32)]
+                ("grad_scale", _f32), ("n", _i64), ("zero_grad", _i32)]
 
 
 _SIGS = {  # name -> (restype, params struct or None)
@@ -140,9 +161,12 @@ _SIGS = {  # name -> (restype, params struct or None)
     "chap_planar_to_cl": PlanarToClParams, "chap_cl_to_planar": ClToPlanarParams,
     "chap_mix_loss_fwd": MixLossParams, "chap_mix_loss_bwd": MixLossParams, "chap_pseudo_block": PseudoParams,
     "chap_kl_fwd_bwd": KlParams, "chap_l2_normalize": L2NormParams, "chap_perturb": AxpyParams,
-    "chap_rand_uniform": RandParams, "chap_keep_mask": KeepMaskParams, "chap_sgd_step": SgdParams,
+    "chap_rand_uniform": RandParams, "chap_keep_mask": KeepMaskParams, "chap_chan_mask": ChanMaskParams,
+    "chap_box_mix": BoxMixParams, "chap_box_mask": BoxMaskParams, "chap_largest_cc": LccParams,
+    "chap_diff_mask": DiffMaskParams, "chap_sgd_step": SgdParams,
 }
-_SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParams, "chap_wgrad_ws": WgradParams}
+_SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParams, "chap_wgrad_ws": WgradParams,
+             "chap_lcc_ws": LccParams}
 
 _lib = None
 

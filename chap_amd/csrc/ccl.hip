@@ -1,0 +1,99 @@
+// Largest connected component per (image, class > 0), 8-connectivity, entirely on the GPU:
+// union-find with atomicMin roots (root = smallest linear index of the component, i.e. the
+// component met first in raster order -- the tie-break of np.argmax(np.bincount(...)) over
+// skimage.measure.label's raster-ordered labels, train_ours_2D.py:134-136).
+#include "common.h"
+
+__device__ __forceinline__ int uf_find(const int* L, int i) {
+    int r = L[i];
+    while (r != i) { i = r; r = L[i]; }
+    return r;
+}
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+    bool done = false;
+    while (!done) {
+        a = uf_find(L, a); b = uf_find(L, b);
+        if (a == b) return;
+        if (a > b) { const int t = a; a = b; b = t; }       // a < b: hang b under a
+        const int old = atomicMin(&L[b], a);
+        done = (old == b);
+        b = old;
+    }
+}
+
+__global__ void lcc_init_kernel(const int64_t* lab, int* L, unsigned* size, unsigned long long* best, long total, int nbest) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        L[i] = lab[i] > 0 ? (int)i : -1;
+        size[i] = 0;
+    }
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nbest; i += (long)gridDim.x * blockDim.x) best[i] = 0ull;
+}
+__global__ void lcc_merge_kernel(const int64_t* lab, int* L, int N, int H, int W) {
+    const long total = (long)N * H * W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int64_t c = lab[i];
+        if (c <= 0) continue;
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        // forward neighbours: E, SW, S, SE (each undirected edge visited once)
+        if (x + 1 < W && lab[i + 1] == c) uf_union(L, (int)i, (int)i + 1);
+        if (y + 1 < H) {
+            if (x > 0 && lab[i + W - 1] == c) uf_union(L, (int)i, (int)(i + W - 1));
+            if (lab[i + W] == c) uf_union(L, (int)i, (int)(i + W));
+            if (x + 1 < W && lab[i + W + 1] == c) uf_union(L, (int)i, (int)(i + W + 1));
+        }
+    }
+}
+__global__ void lcc_count_kernel(int* L, unsigned* size, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (L[i] < 0) continue;
+        const int r = uf_find(L, (int)i);
+        L[i] = r;                                   // path compression; roots keep L[r] == r
+        atomicAdd(&size[r], 1u);
+    }
+}
+__global__ void lcc_best_kernel(const int64_t* lab, const int* L, const unsigned* size, unsigned long long* best, int HW, int ncls, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (L[i] != (int)i) continue;               // roots only
+        const int n = (int)(i / HW);
+        const int c = (int)lab[i];
+        if (c >= ncls) continue;
+        const unsigned long long key = ((unsigned long long)size[i] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        atomicMax(&best[(long)n * ncls + c], key);
+    }
+}
+__global__ void lcc_write_kernel(const int64_t* lab, const int* L, const unsigned long long* best, int64_t* out, int HW, int ncls, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int64_t c = lab[i];
+        int64_t o = 0;
+        if (c > 0 && c < ncls) {
+            const int r = L[i];
+            const unsigned long long b = best[(long)(i / HW) * ncls + c];
+            if ((unsigned)(0xFFFFFFFFu - (unsigned)(b & 0xFFFFFFFFull)) == (unsigned)r) o = c;
+        }
+        out[i] = o;
+    }
+}
+
+extern "C" size_t chap_lcc_ws(const chap_lcc_params* p) {
+    if (!p) return 0;
+    const size_t total = (size_t)p->N * p->H * p->W;
+    return total * (sizeof(int) + sizeof(unsigned)) + ((size_t)p->N * p->num_classes + 8) * sizeof(unsigned long long) + 64;
+}
+extern "C" int chap_largest_cc(const chap_lcc_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->labels && p->out && p->ws, "chap_largest_cc: null argument");
+    const long total = (long)p->N * p->H * p->W;
+    CHAP_CHECK_ARG(total < 0x7FFFFFFFL, "chap_largest_cc: too many pixels");
+    hipStream_t s = (hipStream_t)stream;
+    const int nbest = p->N * p->num_classes;
+    unsigned long long* best = (unsigned long long*)p->ws;                  // 8-byte aligned first
+    int* L = (int*)(best + ((nbest + 7) / 8) * 8);
+    unsigned* size = (unsigned*)(L + total);
+    const int nb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(lcc_init_kernel, dim3(nb), dim3(256), 0, s, p->labels, L, size, best, total, nbest);
+    hipLaunchKernelGGL(lcc_merge_kernel, dim3(nb), dim3(256), 0, s, p->labels, L, p->N, p->H, p->W);
+    hipLaunchKernelGGL(lcc_count_kernel, dim3(nb), dim3(256), 0, s, L, size, total);
+    hipLaunchKernelGGL(lcc_best_kernel, dim3(nb), dim3(256), 0, s, p->labels, (const int*)L, (const unsigned*)size, best, p->H * p->W, p->num_classes, total);
+    hipLaunchKernelGGL(lcc_write_kernel, dim3(nb), dim3(256), 0, s, p->labels, (const int*)L, (const unsigned long long*)best, p->out, p->H * p->W, p->num_classes, total);
+    CHAP_LAUNCH_CHECK("chap_largest_cc");
+    return CHAP_OK;
+}

@@ -51,7 +51,7 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
 }
 
 // ---- weight packing ------------------------------------------------------------------------
-struct pack_geom { int Ck, Cn_logical, ctaps; };
+struct pack_geom { int Ck, Ck_real, Cn_logical, ctaps; };   // Ck = K channels padded to 16 (tiny heads)
 static int pack_geometry(const chap_pack_params* p, pack_geom* g) {
     switch (p->kind) {
         case CHAP_PACK_CONV_FWD:     g->Ck = p->Cin;  g->Cn_logical = p->Cout;           g->ctaps = p->taps; break;
@@ -61,12 +61,14 @@ static int pack_geometry(const chap_pack_params* p, pack_geom* g) {
         case CHAP_PACK_DOWN_DGRAD:   g->Ck = p->Cout; g->Cn_logical = p->taps * p->Cin;  g->ctaps = 1;       break;
         default: chap_set_error("chap_pack: kind=%d", p->kind); return CHAP_EINVAL;
     }
+    g->Ck_real = g->Ck;
+    g->Ck = (g->Ck + 15) / 16 * 16;
     return CHAP_OK;
 }
 
 template <typename T>
 __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ out, int kind, int Cin, int Cout, int taps,
-                            int KC, int GPT, int NP, int STEPS, int nchunks, int ntiles, int Cn_logical) {
+                            int KC, int GPT, int NP, int STEPS, int nchunks, int ntiles, int Cn_logical, int Ck_real) {
     const long total = (long)nchunks * STEPS * ntiles * 64;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int lane = (int)(i & 63);
@@ -83,7 +85,8 @@ __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ out, in
             float x = 0.f;
             if (pp < NP && nl < Cn_logical) {
                 const int tap = pp / GPT, c = chunk * KC + (pp % GPT) * 8 + j;
-                long a;
+                long a = -1;
+                if (c < Ck_real)
                 switch (kind) {
                     case CHAP_PACK_CONV_FWD:     a = ((long)nl * Cin + c) * taps + tap; break;
                     case CHAP_PACK_CONV_DGRAD:   a = ((long)c * Cin + nl) * taps + (taps - 1 - tap); break;
@@ -91,7 +94,7 @@ __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ out, in
                     case CHAP_PACK_DECONV_DGRAD: a = ((long)nl * Cout + c) * taps + tap; break;
                     default:                     a = ((long)c * Cin + (nl % Cin)) * taps + (nl / Cin); break;  // DOWN_DGRAD
                 }
-                x = w[a];
+                if (a >= 0) x = w[a];
             }
             v[j] = x;
         }
@@ -118,10 +121,10 @@ extern "C" int chap_pack_weights(const chap_pack_params* p, void* stream) {
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     if (p->dtype == CHAP_BF16)
         hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p->w, (bf16_t*)p->out, p->kind, p->Cin, p->Cout, p->taps,
-                           b.KC, b.GPT, b.NP, b.STEPS, b.nchunks, b.ntiles, g.Cn_logical);
+                           b.KC, b.GPT, b.NP, b.STEPS, b.nchunks, b.ntiles, g.Cn_logical, g.Ck_real);
     else if (p->dtype == CHAP_F32)
         hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p->w, (float*)p->out, p->kind, p->Cin, p->Cout, p->taps,
-                           b.KC, b.GPT, b.NP, b.STEPS, b.nchunks, b.ntiles, g.Cn_logical);
+                           b.KC, b.GPT, b.NP, b.STEPS, b.nchunks, b.ntiles, g.Cn_logical, g.Ck_real);
     else { chap_set_error("chap_pack_weights: dtype=%d", p->dtype); return CHAP_EINVAL; }
     CHAP_LAUNCH_CHECK("chap_pack_weights");
     return CHAP_OK;

@@ -1,0 +1,224 @@
+// Segmentation-loss kernels on fp32 planar logits [N][C][P] (C <= 8): one thread per pixel keeps
+// the C logits in registers, softmax in registers, wave64 shuffle reductions, one float atomic per
+// block and accumulator.  HBM-bound: each logit is read once per pass.
+#include "common.h"
+
+
+
+template <int C>
+__device__ __forceinline__ void softmax_px(const float* __restrict__ lg, long base, long P, float z[C], float p[C], float& lse) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { z[c] = lg[base + c * P]; m = fmaxf(m, z[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { p[c] = expf(z[c] - m); s += p[c]; }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] *= inv;
+    lse = m + logf(s);
+}
+
+// acc layout per part k in {a, b}: [0] ce_sum, [1..C] I_c, [1+C..2C] Z_c, [1+2C..3C] Y_c, [1+3C] msum
+template <int C>
+__global__ __launch_bounds__(256) void mix_loss_acc_kernel(const chap_mix_loss_params P_) {
+    constexpr int NA = 2 + 3 * C;
+    __shared__ float red[2 * NA];
+    for (int i = threadIdx.x; i < 2 * NA; i += 256) red[i] = 0.f;
+    __syncthreads();
+    float a[2][NA];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a[k][i] = 0.f;
+    const long P = P_.P, total = (long)P_.N * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / P, pp = i % P;
+        float z[C], p[C], lse;
+        softmax_px<C>(P_.logits, n * C * P + pp, P, z, p, lse);
+        const float m = (float)P_.mask[i];
+        const int t[2] = {(int)P_.target_a[i], (int)P_.target_b[i]};
+        const float mk[2] = {m, 1.f - m};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float zt = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float tc = (t[k] == c) ? 1.f : 0.f;
+                zt += tc * z[c];
+                a[k][1 + c] += p[c] * tc * mk[k];
+                a[k][1 + C + c] += p[c] * p[c] * mk[k];
+                a[k][1 + 2 * C + c] += tc * mk[k];
+            }
+            a[k][0] += (lse - zt) * mk[k];
+            a[k][1 + 3 * C] += mk[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const float v = wave_sum(a[k][i]);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&red[k * NA + i], v);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * NA; i += 256) atomicAdd(&P_.acc[i], red[i]);
+}
+
+// mix_loss return triple (train_ours_2D.py:205-216) from the accumulators.
+__global__ void mix_loss_final_kernel(const float* acc, float* loss, int C, float w_a, float w_b, float smooth) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int NA = 2 + 3 * C;
+    float part[2];
+    const float w[2] = {w_a, w_b};
+    for (int k = 0; k < 2; ++k) {
+        const float* a = acc + k * NA;
+        float dice = 0.f;
+        for (int c = 0; c < C; ++c) dice += 1.f - (2.f * a[1 + c] + smooth) / (a[1 + C + c] + a[1 + 2 * C + c] + smooth);
+        dice = dice / C * w[k];
+        const float ce = w[k] * a[0] / (a[1 + 3 * C] + 1e-16f);
+        part[k] = 0.5f * (dice + ce);
+    }
+    loss[0] = part[0]; loss[1] = part[1]; loss[2] = part[0] + part[1];
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void mix_loss_bwd_kernel(const chap_mix_loss_params P_) {
+    constexpr int NA = 2 + 3 * C;
+    __shared__ float sa[2 * NA];
+    for (int i = threadIdx.x; i < 2 * NA; i += 256) sa[i] = P_.acc[i];
+    __syncthreads();
+    const long P = P_.P, total = (long)P_.N * P;
+    const float w[2] = {P_.w_a, P_.w_b};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / P, pp = i % P;
+        float z[C], p[C], lse;
+        softmax_px<C>(P_.logits, n * C * P + pp, P, z, p, lse);
+        const float m = (float)P_.mask[i];
+        const int t[2] = {(int)P_.target_a[i], (int)P_.target_b[i]};
+        const float mk[2] = {m, 1.f - m};
+        float dz[C], dp[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) { dz[c] = 0.f; dp[c] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const float* a = sa + k * NA;
+            const float kce = w[k] * mk[k] / (a[1 + 3 * C] + 1e-16f);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float tc = (t[k] == c) ? 1.f : 0.f;
+                dz[c] += kce * (p[c] - tc);
+                const float den = a[1 + C + c] + a[1 + 2 * C + c] + P_.smooth;
+                dp[c] += (w[k] / C) * mk[k] * (-2.f * tc / den + (2.f * a[1 + c] + P_.smooth) * 2.f * p[c] / (den * den));
+            }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) dot += dp[c] * p[c];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float gz = 0.5f * P_.gscale * (dz[c] + p[c] * (dp[c] - dot));
+            float* o = P_.dlogits + n * C * P + c * P + pp;
+            *o = P_.accumulate ? *o + gz : gz;
+        }
+    }
+}
+
+static int loss_blocks(long total) { long b = (total + 255) / 256; return (int)(b < 2048 ? b : 2048); }
+
+extern "C" int chap_mix_loss_fwd(const chap_mix_loss_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->logits && p->target_a && p->target_b && p->mask && p->acc && p->loss, "chap_mix_loss_fwd: null argument");
+    CHAP_CHECK_ARG(p->C == 4 || p->C == 2, "chap_mix_loss: C=%d (2 or 4 built)", p->C);
+    const int nb = loss_blocks((long)p->N * p->P);
+    hipStream_t s = (hipStream_t)stream;
+    if (p->C == 4) hipLaunchKernelGGL(mix_loss_acc_kernel<4>, dim3(nb), dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL(mix_loss_acc_kernel<2>, dim3(nb), dim3(256), 0, s, *p);
+    CHAP_LAUNCH_CHECK("chap_mix_loss_fwd");
+    hipLaunchKernelGGL(mix_loss_final_kernel, dim3(1), dim3(64), 0, s, (const float*)p->acc, p->loss, p->C, p->w_a, p->w_b, p->smooth);
+    CHAP_LAUNCH_CHECK("chap_mix_loss_fwd(final)");
+    return CHAP_OK;
+}
+extern "C" int chap_mix_loss_bwd(const chap_mix_loss_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->logits && p->target_a && p->target_b && p->mask && p->acc && p->dlogits, "chap_mix_loss_bwd: null argument");
+    CHAP_CHECK_ARG(p->C == 4 || p->C == 2, "chap_mix_loss: C=%d (2 or 4 built)", p->C);
+    const int nb = loss_blocks((long)p->N * p->P);
+    if (p->C == 4) hipLaunchKernelGGL(mix_loss_bwd_kernel<4>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(mix_loss_bwd_kernel<2>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_mix_loss_bwd");
+    return CHAP_OK;
+}
+
+// pass-A pseudo-label block (train_ours_2D.py:319-325)
+template <int C>
+__global__ __launch_bounds__(256) void pseudo_kernel(const chap_pseudo_params P_) {
+    const long P = P_.P, total = (long)P_.N * P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / P, pp = i % P, base = n * C * P + pp;
+        float z1[C], p1[C], l1, z2[C], p2[C], l2;
+        softmax_px<C>(P_.logits1, base, P, z1, p1, l1);
+        softmax_px<C>(P_.logits2, base, P, z2, p2, l2);
+        int a1 = 0, a2 = 0;
+#pragma unroll
+        for (int c = 1; c < C; ++c) { if (p1[c] > p1[a1]) a1 = c; if (p2[c] > p2[a2]) a2 = c; }   // first max wins (torch.argmax)
+        if (P_.soft1) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) { P_.soft1[base + c * P] = p1[c]; P_.soft2[base + c * P] = p2[c]; }
+        }
+        if (P_.arg1) { P_.arg1[i] = a1; P_.arg2[i] = a2; }
+        if (P_.knowledge) {
+            float za = 0.f, zb = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { za += (c == a2) ? z1[c] : 0.f; zb += (c == a1) ? z2[c] : 0.f; }
+            P_.knowledge[i] = (l1 - za) + (l2 - zb);
+        }
+    }
+}
+extern "C" int chap_pseudo_block(const chap_pseudo_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->logits1 && p->logits2, "chap_pseudo_block: null argument");
+    CHAP_CHECK_ARG(p->C == 4 || p->C == 2, "chap_pseudo_block: C=%d (2 or 4 built)", p->C);
+    CHAP_CHECK_ARG((p->soft1 == nullptr) == (p->soft2 == nullptr) && (p->arg1 == nullptr) == (p->arg2 == nullptr), "chap_pseudo_block: outputs come in pairs");
+    const int nb = loss_blocks((long)p->N * p->P);
+    if (p->C == 4) hipLaunchKernelGGL(pseudo_kernel<4>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(pseudo_kernel<2>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_pseudo_block");
+    return CHAP_OK;
+}
+
+// KL(target || softmax(logits)), mean over N*P, summed over the two heads; gradient wrt logits.
+template <int C>
+__global__ __launch_bounds__(256) void kl_kernel(const chap_kl_params P_) {
+    __shared__ float red;
+    if (threadIdx.x == 0) red = 0.f;
+    __syncthreads();
+    const long P = P_.P, total = (long)P_.N * P;
+    const float inv = 1.f / (float)total;
+    const float gs = P_.gscale * (P_.gscale_dev ? *P_.gscale_dev : 1.f) * inv;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / P, pp = i % P, base = n * C * P + pp;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float z[C], p[C], lse;
+            softmax_px<C>(P_.logits[h], base, P, z, p, lse);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float t = P_.target[h][base + c * P];
+                if (t > 0.f) acc += t * (logf(t) - (z[c] - lse));
+                if (P_.dlogits[h]) P_.dlogits[h][base + c * P] = gs * (p[c] - t);
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&red, acc);
+    __syncthreads();
+    if (threadIdx.x == 0 && P_.loss) atomicAdd(P_.loss, red * inv);
+}
+extern "C" int chap_kl_fwd_bwd(const chap_kl_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->logits[0] && p->logits[1] && p->target[0] && p->target[1], "chap_kl_fwd_bwd: null argument");
+    CHAP_CHECK_ARG(p->C == 4 || p->C == 2, "chap_kl_fwd_bwd: C=%d (2 or 4 built)", p->C);
+    const int nb = loss_blocks((long)p->N * p->P);
+    if (p->C == 4) hipLaunchKernelGGL(kl_kernel<4>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(kl_kernel<2>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_kl_fwd_bwd");
+    return CHAP_OK;
+}

@@ -109,7 +109,7 @@ def conv_c1_bwd(g, w, x, *, dims, dx=None, dw=None, db=None):
     L.call("chap_conv_c1_bwd", p, _stream())
 
 
-def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine=0, db=None):
+def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine=0, db=None, kc_valid=0, kn_valid=0):
     p = L.WgradParams()
     for i, s in enumerate(a_srcs):
         s.fill(p.a[i])
@@ -121,6 +121,7 @@ def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine
     p.dw = dw.data_ptr()
     p.s_tap, p.s_kc, p.s_kn = strides
     p.db = _p(db)
+    p.kc_valid, p.kn_valid = kc_valid, kn_valid
     p.dtype = dt(b.raw)
     nbytes = L.size_of("chap_wgrad_ws", p)
     ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dw.device)
@@ -211,3 +212,130 @@ def cl_to_planar(lazy, out):
     lazy.fill(p.r)
     p.out, p.N, p.P, p.dtype = out.data_ptr(), lazy.raw.shape[0], lazy.raw[0, ..., 0].numel(), dt(lazy.raw)
     L.call("chap_cl_to_planar", p, _stream())
+
+
+# ------------------------------------------------------------------------------------------
+# losses / training-loop helpers (fp32 planar logits [N, C, *spatial])
+def mix_loss_fwd(logits, target_a, target_b, mask, w_a, w_b, smooth=1e-10):
+    """Returns (loss[3] = (loss_a, loss_b, total), acc) -- acc is needed by mix_loss_bwd."""
+    N, Cc = logits.shape[0], logits.shape[1]
+    p = L.MixLossParams()
+    acc = torch.zeros(2 * (2 + 3 * Cc), dtype=torch.float32, device=logits.device)
+    loss = torch.empty(3, dtype=torch.float32, device=logits.device)
+    p.logits, p.target_a, p.target_b, p.mask = logits.data_ptr(), target_a.data_ptr(), target_b.data_ptr(), mask.data_ptr()
+    p.w_a, p.w_b, p.acc, p.loss = w_a, w_b, acc.data_ptr(), loss.data_ptr()
+    p.N, p.C, p.P, p.smooth = N, Cc, logits[0, 0].numel(), smooth
+    L.call("chap_mix_loss_fwd", p, _stream())
+    return loss, acc
+
+
+def mix_loss_bwd(logits, target_a, target_b, mask, w_a, w_b, acc, dlogits, gscale=1.0, accumulate=False, smooth=1e-10):
+    N, Cc = logits.shape[0], logits.shape[1]
+    p = L.MixLossParams()
+    p.logits, p.target_a, p.target_b, p.mask = logits.data_ptr(), target_a.data_ptr(), target_b.data_ptr(), mask.data_ptr()
+    p.w_a, p.w_b, p.acc, p.dlogits = w_a, w_b, acc.data_ptr(), dlogits.data_ptr()
+    p.gscale, p.accumulate = gscale, int(accumulate)
+    p.N, p.C, p.P, p.smooth = N, Cc, logits[0, 0].numel(), smooth
+    L.call("chap_mix_loss_bwd", p, _stream())
+
+
+def pseudo_block(logits1, logits2, want_soft=True):
+    N, Cc = logits1.shape[0], logits1.shape[1]
+    sp = logits1.shape[2:]
+    dev = logits1.device
+    soft1 = torch.empty_like(logits1) if want_soft else None
+    soft2 = torch.empty_like(logits2) if want_soft else None
+    arg1 = torch.empty((N,) + tuple(sp), dtype=torch.int64, device=dev)
+    arg2 = torch.empty_like(arg1)
+    know = torch.empty((N,) + tuple(sp), dtype=torch.float32, device=dev)
+    p = L.PseudoParams()
+    p.logits1, p.logits2, p.soft1, p.soft2 = logits1.data_ptr(), logits2.data_ptr(), _p(soft1), _p(soft2)
+    p.arg1, p.arg2, p.knowledge = arg1.data_ptr(), arg2.data_ptr(), know.data_ptr()
+    p.N, p.C, p.P = N, Cc, logits1[0, 0].numel()
+    L.call("chap_pseudo_block", p, _stream())
+    return soft1, soft2, arg1, arg2, know
+
+
+def kl_fwd_bwd(logits, targets, loss, dlogits=(None, None), gscale=1.0, gscale_dev=None):
+    """loss (1-elem fp32 tensor) += mean_{n,p} sum_heads KL(target || softmax(logits))."""
+    p = L.KlParams()
+    for h in range(2):
+        p.logits[h], p.target[h], p.dlogits[h] = logits[h].data_ptr(), targets[h].data_ptr(), _p(dlogits[h])
+    p.loss, p.gscale, p.gscale_dev = _p(loss), gscale, _p(gscale_dev)
+    p.N, p.C, p.P = logits[0].shape[0], logits[0].shape[1], logits[0][0, 0].numel()
+    L.call("chap_kl_fwd_bwd", p, _stream())
+
+
+def l2_normalize(x, out, eps=1e-8):
+    p = L.L2NormParams()
+    p.in_, p.out, p.N, p.P, p.eps = x.data_ptr(), out.data_ptr(), x.shape[0], x[0].numel(), eps
+    L.call("chap_l2_normalize", p, _stream())
+
+
+def perturb(x, d, out, alpha, mask=None, sign=False):
+    p = L.AxpyParams()
+    p.x, p.d, p.mask, p.out = x.data_ptr(), d.data_ptr(), _p(mask), out.data_ptr()
+    p.alpha, p.sign, p.n = alpha, int(sign), x.numel()
+    L.call("chap_perturb", p, _stream())
+
+
+def rand_uniform(out, seed, lo=0.0, hi=1.0, seed_dev=None):
+    p = L.RandParams()
+    p.out, p.seed, p.seed_dev, p.n, p.lo, p.hi = out.data_ptr(), seed, _p(seed_dev), out.numel(), lo, hi
+    L.call("chap_rand_uniform", p, _stream())
+
+
+def keep_mask(keep, seed, prob, seed_dev=None):
+    p = L.KeepMaskParams()
+    p.keep, p.seed, p.seed_dev, p.n, p.p = keep.data_ptr(), seed, _p(seed_dev), keep.numel(), prob
+    L.call("chap_keep_mask", p, _stream())
+
+
+def chan_mask(mul, seed, prob, seed_dev=None):
+    p = L.ChanMaskParams()
+    p.mul, p.seed, p.seed_dev, p.n, p.p = mul.data_ptr(), seed, _p(seed_dev), mul.numel(), prob
+    L.call("chap_chan_mask", p, _stream())
+
+
+def box_mix(a, b, out, box):
+    """out = inside box ? b : a ; a/b/out [N, (1,) H, W] float32 or int64; box: device int32[4]."""
+    p = L.BoxMixParams()
+    p.a, p.b, p.out, p.box = a.data_ptr(), b.data_ptr(), out.data_ptr(), box.data_ptr()
+    p.N, p.H, p.W, p.is_i64 = a.shape[0], a.shape[-2], a.shape[-1], int(a.dtype == torch.int64)
+    L.call("chap_box_mix", p, _stream())
+
+
+def box_mask(mask, box):
+    p = L.BoxMaskParams()
+    p.mask, p.box, p.N, p.H, p.W = mask.data_ptr(), box.data_ptr(), mask.shape[0], mask.shape[-2], mask.shape[-1]
+    L.call("chap_box_mask", p, _stream())
+
+
+def largest_cc(labels, num_classes):
+    """labels int64 [N, H, W] -> int64 [N, H, W] keeping the largest 8-connected component per class."""
+    out = torch.empty_like(labels)
+    p = L.LccParams()
+    p.labels, p.out = labels.data_ptr(), out.data_ptr()
+    p.N, p.H, p.W, p.num_classes = labels.shape[0], labels.shape[1], labels.shape[2], num_classes
+    ws = torch.empty(L.size_of("chap_lcc_ws", p), dtype=torch.uint8, device=labels.device)
+    p.ws = ws.data_ptr()
+    L.call("chap_largest_cc", p, _stream())
+    return out
+
+
+def diff_mask(p1, p2, knowledge, scale, topk):
+    N, H, W = knowledge.shape
+    out = torch.empty(N, H, W, dtype=torch.float32, device=knowledge.device)
+    ws = torch.empty(N, H // scale, W // scale, dtype=torch.float32, device=knowledge.device)
+    p = L.DiffMaskParams()
+    p.p1, p.p2, p.knowledge, p.out, p.pooled_ws = p1.data_ptr(), p2.data_ptr(), knowledge.data_ptr(), out.data_ptr(), ws.data_ptr()
+    p.N, p.H, p.W, p.scale, p.topk = N, H, W, scale, topk
+    L.call("chap_diff_mask", p, _stream())
+    return out
+
+
+def sgd_step(param, grad, mom, lr_dev, momentum, weight_decay, grad_scale=1.0, zero_grad=True):
+    p = L.SgdParams()
+    p.param, p.grad, p.mom, p.lr = param.data_ptr(), grad.data_ptr(), mom.data_ptr(), lr_dev.data_ptr()
+    p.momentum, p.weight_decay, p.grad_scale, p.n, p.zero_grad = momentum, weight_decay, grad_scale, param.numel(), int(zero_grad)
+    L.call("chap_sgd_step", p, _stream())

@@ -151,7 +151,7 @@ typedef struct {
     int32_t     ksize, stride, dims;
     float*      dw;            /* accumulated: dw[tap*s_tap + kc*s_kc + kn*s_kn] += ...           */
     int64_t     s_tap, s_kc, s_kn;
-    int32_t     flip;          /* unused for forward-geometry wgrad; reserved                     */
+    int32_t     kc_valid, kn_valid; /* write only kc < kc_valid, kn < kn_valid (0 = all): padded heads */
     float*      db;            /* [Cb] += or NULL                                                 */
     void*       ws;  size_t ws_bytes;
     int32_t     dtype;
@@ -253,24 +253,51 @@ int chap_pseudo_block(const chap_pseudo_params* p, void* stream);
 typedef struct {               /* KL(target || softmax(logits)) summed over both heads, / (N*P)  */
     const float* logits[2]; const float* target[2];
     float* loss;  float* dlogits[2];  /* loss += ; dlogits may be NULL                            */
-    float gscale; int32_t N, C, P;
+    float gscale; const float* gscale_dev;   /* gradient scale = gscale * (*gscale_dev if given) */
+    int32_t N, C, P;
 } chap_kl_params;
 int chap_kl_fwd_bwd(const chap_kl_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * VAT perturbation helpers (per-sample L2 normalise, masked axpy, sign step).               */
+ * VAT perturbation helpers (losses.VAT2d is ABSENT from the reference; semantics defined in
+ * DESIGN.md "P1"): per-sample L2 normalise, masked axpy / sign step, counter-based RNG.
+ * `seed_dev` (optional, device uint64) is added to `seed` so a captured graph draws new numbers
+ * on every replay once the host bumps that word. */
 typedef struct { const float* in; float* out; int32_t N, P; float eps; } chap_l2norm_params;
 int chap_l2_normalize(const chap_l2norm_params* p, void* stream);   /* out[n] = in[n]/(||in[n]||+eps) */
 typedef struct { const float* x; const float* d; const float* mask; float* out; float alpha; int32_t sign; int64_t n; } chap_axpy_params;
 int chap_perturb(const chap_axpy_params* p, void* stream);          /* out = x + alpha*mask*(sign? sgn(d): d) */
-typedef struct { float* out; uint64_t seed; int64_t n; float lo, hi; } chap_rand_params;
+typedef struct { float* out; uint64_t seed; const uint64_t* seed_dev; int64_t n; float lo, hi; } chap_rand_params;
 int chap_rand_uniform(const chap_rand_params* p, void* stream);
-typedef struct { uint8_t* keep; uint64_t seed; int64_t n; float p; } chap_keepmask_params;
-int chap_keep_mask(const chap_keepmask_params* p, void* stream);
+typedef struct { uint8_t* keep; uint64_t seed; const uint64_t* seed_dev; int64_t n; float p; } chap_keepmask_params;
+int chap_keep_mask(const chap_keepmask_params* p, void* stream);     /* keep[i] = u(i) >= p */
+typedef struct { float* mul; uint64_t seed; const uint64_t* seed_dev; int64_t n; float p; } chap_chanmask_params;
+int chap_chan_mask(const chap_chanmask_params* p, void* stream);     /* mul[i] = u(i) >= p ? 1/(1-p) : 0  (Dropout3d) */
 
-/* Fused SGD(momentum, weight decay) over a flat fp32 parameter buffer (train_ours_2D.py:278,383).
+/* BCP copy-paste mixing (train_ours_2D.py:91-101, 331-338). box = device int32[4] {y0, x0, bh, bw}:
+ * out = inside box ? b : a  (mask is 0 inside the box: a*mask + b*(1-mask)). */
+typedef struct { const void* a; const void* b; void* out; const int32_t* box; int32_t N, H, W; int32_t is_i64; } chap_boxmix_params;
+int chap_box_mix(const chap_boxmix_params* p, void* stream);
+typedef struct { int64_t* mask; const int32_t* box; int32_t N, H, W; } chap_boxmask_params;
+int chap_box_mask(const chap_boxmask_params* p, void* stream);       /* loss_mask: 0 inside the box, 1 outside */
+
+/* Largest connected component per (image, class>0), 8-connectivity (skimage.measure.label default),
+ * get_ACDC_2DLargestCC (train_ours_2D.py:123-144) without the 72 device->host round trips.
+ * labels/out: int64 [N][H][W]; ws: chap_lcc_ws() bytes. Ties: the component met first in raster order. */
+typedef struct { const int64_t* labels; int64_t* out; void* ws; int32_t N, H, W, num_classes; } chap_lcc_params;
+size_t chap_lcc_ws(const chap_lcc_params* p);
+int    chap_largest_cc(const chap_lcc_params* p, void* stream);
+
+/* patch.create_maskV1 (ABSENT from the reference; DESIGN.md "P2"): mask = (p1 != p2) OR
+ * nearest-upsample(top-k fraction of avg_pool(knowledge, scale)), per sample. out fp32 [N][H][W]. */
+typedef struct { const int64_t* p1; const int64_t* p2; const float* knowledge; float* out; float* pooled_ws;
+                 int32_t N, H, W, scale; float topk; } chap_diffmask_params;
+int chap_diff_mask(const chap_diffmask_params* p, void* stream);
+
+/* Fused SGD(momentum, weight decay) over a flat fp32 parameter buffer (train_ours_2D.py:278,383):
+ * g = grad*grad_scale + wd*p; m = mu*m + g; p -= lr*m; optionally grad = 0.
  * lr is read from device memory so a captured graph can be replayed with a new value. */
-typedef struct { float* param; float* grad; float* mom; const float* lr; float momentum, weight_decay, grad_scale; int64_t n; int32_t first; } chap_sgd_params;
+typedef struct { float* param; float* grad; float* mom; const float* lr; float momentum, weight_decay, grad_scale; int64_t n; int32_t zero_grad; } chap_sgd_params;
 int chap_sgd_step(const chap_sgd_params* p, void* stream);
 
 const char* chap_last_error(void);

@@ -1,0 +1,155 @@
+"""CPU restatement of one iteration of code/train_ours_2D.py:301-389 (TEST INFRASTRUCTURE ONLY).
+
+Present in the reference and restated from the cited lines (formula-level pin, the script itself
+cannot be imported -- absent in-repo modules):
+    mix_loss                 train_ours_2D.py:198-216
+    generate_mask            train_ours_2D.py:91-101   (box offsets are an INPUT here)
+    get_ACDC_masks / LCC     train_ours_2D.py:103-108, 123-144  (scipy.ndimage.label with a full 3x3
+                             structure == skimage.measure.label default connectivity)
+    pseudo-label block       train_ours_2D.py:314-325
+    BCP mixing               train_ours_2D.py:331-338
+    SGD + poly LR            train_ours_2D.py:278, 381-389
+ABSENT from the reference ("parity unpinned"; defined by this build):
+    dice_loss_bcp   (losses.DiceLoss_bcp)   masked multi-class Dice, smooth 1e-10
+    vat2d           (losses.VAT2d)          VAT power iteration on the unlabeled half
+    create_mask_v1  (patch.create_maskV1)   disagreement OR top-k of the 4x-pooled knowledge map
+    sigmoid_rampup  (ramps.sigmoid_rampup)  exp(-5 (1 - t)^2)
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+DICE_SMOOTH = 1e-10
+
+
+def sigmoid_rampup(current, rampup_length):
+    """Laine & Aila ramp-up (cited at train_ours_2D.py:35)."""
+    if rampup_length == 0:
+        return 1.0
+    t = float(np.clip(current, 0.0, rampup_length)) / rampup_length
+    return float(math.exp(-5.0 * (1.0 - t) ** 2))
+
+
+def consistency_weight(iter_num, consistency=1.0, rampup=50.0):
+    return consistency * sigmoid_rampup(iter_num // 150, rampup)     # train_ours_2D.py:34-36,356
+
+
+def poly_lr(base_lr, iter_num, max_iterations):
+    return base_lr * (1.0 - iter_num / max_iterations) ** 0.9        # train_ours_2D.py:387
+
+
+def dice_loss_bcp(soft, target, mask, n_classes):
+    """soft [N,C,...], target [N,...] int, mask [N,...] -> mean_c 1 - (2 I_c + s)/(Z_c + Y_c + s)."""
+    loss = 0.0
+    m = mask.to(soft.dtype)
+    for c in range(n_classes):
+        t = (target == c).to(soft.dtype)
+        p = soft[:, c]
+        inter = (p * t * m).sum()
+        z = (p * p * m).sum()
+        y = (t * t * m).sum()
+        loss = loss + (1.0 - (2.0 * inter + DICE_SMOOTH) / (z + y + DICE_SMOOTH))
+    return loss / n_classes
+
+
+def mix_loss(output, img_l, patch_l, mask, l_weight=1.0, u_weight=0.5, unlab=False):
+    """-> (loss_image, loss_patch, total) exactly as train_ours_2D.py:198-216."""
+    n_classes = output.shape[1]
+    img_l, patch_l = img_l.long(), patch_l.long()
+    soft = F.softmax(output, dim=1)
+    iw, pw = (u_weight, l_weight) if unlab else (l_weight, u_weight)
+    m = mask.to(output.dtype)
+    pm = 1.0 - m
+    d1 = dice_loss_bcp(soft, img_l, m, n_classes) * iw
+    d2 = dice_loss_bcp(soft, patch_l, pm, n_classes) * pw
+    ce1 = iw * (F.cross_entropy(output, img_l, reduction="none") * m).sum() / (m.sum() + 1e-16)
+    ce2 = pw * (F.cross_entropy(output, patch_l, reduction="none") * pm).sum() / (pm.sum() + 1e-16)
+    return (d1 + ce1) / 2.0, (d2 + ce2) / 2.0, (d1 + d2 + ce1 + ce2) / 2.0
+
+
+def box_masks(n, h, w, y0, x0, dtype=torch.float32):
+    """generate_mask with explicit offsets: zero box of int(2H/3) x int(2W/3) at (y0, x0)."""
+    ph, pw = int(h * 2 / 3), int(w * 2 / 3)
+    mask = torch.ones(h, w, dtype=dtype)
+    mask[y0:y0 + ph, x0:x0 + pw] = 0
+    return mask, mask.unsqueeze(0).repeat(n, 1, 1)
+
+
+def largest_cc(seg, n_classes):
+    """seg int [N,H,W] -> keep, per sample and class 1..C-1, the largest 8-connected component."""
+    from scipy import ndimage
+    seg = seg.cpu().numpy()
+    out = np.zeros_like(seg)
+    full = np.ones((3, 3), dtype=bool)
+    for i in range(seg.shape[0]):
+        for c in range(1, n_classes):
+            lab, n = ndimage.label(seg[i] == c, structure=full)
+            if n == 0:
+                continue
+            best = np.argmax(np.bincount(lab.flat)[1:]) + 1
+            out[i][lab == best] = c
+    return torch.from_numpy(out)
+
+
+def pseudo_block(pre1, pre2):
+    soft1, soft2 = F.softmax(pre1, 1), F.softmax(pre2, 1)
+    arg1, arg2 = soft1.argmax(1), soft2.argmax(1)
+    know = F.cross_entropy(pre1, arg2, reduction="none") + F.cross_entropy(pre2, arg1, reduction="none")
+    return soft1, soft2, arg1, arg2, know
+
+
+def create_mask_v1(p1, p2, knowledge, scale_factor=4, topk=0.1):
+    """(p1 != p2) OR nearest-upsample(top-k fraction of avg_pool(knowledge, scale)) -> float [N,H,W]."""
+    n, h, w = knowledge.shape
+    pooled = F.avg_pool2d(knowledge.unsqueeze(1), scale_factor).squeeze(1).clamp_min(0)
+    m = pooled[0].numel()
+    k = max(int(topk * m), 1)
+    thr = pooled.reshape(n, -1).topk(k, dim=1).values[:, -1]
+    sel = (pooled >= thr.view(n, 1, 1)).float()
+    sel = F.interpolate(sel.unsqueeze(1), scale_factor=scale_factor, mode="nearest").squeeze(1)
+    return ((sel > 0) | (p1 != p2)).float()
+
+
+def l2_normalize(d, eps=1e-8):
+    n = d.reshape(d.shape[0], -1).norm(dim=1).view(-1, *([1] * (d.dim() - 1)))
+    return d / (n + eps)
+
+
+def kl_two_heads(logits, targets):
+    """sum over heads of mean_{n,pixel} KL(target || softmax(logits))."""
+    tot = 0.0
+    for lg, t in zip(logits, targets):
+        logp = F.log_softmax(lg, 1)
+        kl = torch.where(t > 0, t * (torch.log(t.clamp_min(1e-38)) - logp), torch.zeros_like(t)).sum(1)
+        tot = tot + kl.mean()
+    return tot
+
+
+def vat2d(model_fn, x, soft1, soft2, mask, d0, xi=10.0, eps=6.0, k=1, sign=False):
+    """model_fn(x) -> (logits1, logits2) in train mode WITHOUT running-stat updates.
+    d0: initial noise in [-0.5, 0.5) (injected). mask [N,1,...] or None. Returns (loss, r_adv)."""
+    d = l2_normalize(d0)
+    for _ in range(k):
+        d = d.detach().requires_grad_(True)
+        dist = kl_two_heads(model_fn(x + xi * d), (soft1, soft2))
+        g, = torch.autograd.grad(dist, d)
+        d = l2_normalize(g)
+    d = d.detach()
+    if sign:
+        r = eps / math.sqrt(d[0].numel()) * torch.sign(d)
+    else:
+        r = eps * d
+    if mask is not None:
+        r = r * mask
+    return kl_two_heads(model_fn(x + r), (soft1, soft2)), r
+
+
+def sgd_step(params, grads, moms, lr, momentum=0.9, weight_decay=1e-4):
+    """torch.optim.SGD(momentum, weight_decay), dampening 0, no nesterov; moms start at zero."""
+    with torch.no_grad():
+        for p, g, m in zip(params, grads, moms):
+            gg = g + weight_decay * p
+            m.mul_(momentum).add_(gg)
+            p.sub_(lr * m)
