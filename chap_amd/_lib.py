@@ -88,7 +88,11 @@ class UpsampleBwdParams(C.Structure):
 
 
 class PlanarToClParams(C.Structure):
-    _fields_ = [("in_", _vp), ("out", _vp), ("N", _i32), ("C", _i32), ("P", _i32), ("out_ld", _i32), ("out_coff", _i32), ("dtype", _i32)]
+    _fields_ = [("in_", _vp), ("out", _vp), ("N", _i32), ("C", _i32), ("P", _i32), ("out_ld", _i32), ("out_coff", _i32), ("Cpad", _i32), ("dtype", _i32)]
+
+
+class ChanSumParams(C.Structure):
+    _fields_ = [("r", Src), ("out", _vp), ("npix", _i64), ("pix_per_sample", _i64), ("dtype", _i32)]
 
 
 class ClToPlanarParams(C.Structure):
@@ -158,7 +162,7 @@ _SIGS = {  # name -> (restype, params struct or None)
     "chap_conv_c1_bwd": ConvC1BwdParams, "chap_wgrad": WgradParams, "chap_bn_finalize": BnFinalizeParams,
     "chap_bn_eval_affine": BnEvalParams, "chap_act_bwd_reduce": ActBwdParams, "chap_act_bwd_apply": ActBwdParams,
     "chap_act_pool2": PoolParams, "chap_upsample2x": UpsampleParams, "chap_upsample2x_bwd": UpsampleBwdParams,
-    "chap_planar_to_cl": PlanarToClParams, "chap_cl_to_planar": ClToPlanarParams,
+    "chap_planar_to_cl": PlanarToClParams, "chap_channel_sum": ChanSumParams, "chap_cl_to_planar": ClToPlanarParams,
     "chap_mix_loss_fwd": MixLossParams, "chap_mix_loss_bwd": MixLossParams, "chap_pseudo_block": PseudoParams,
     "chap_kl_fwd_bwd": KlParams, "chap_l2_normalize": L2NormParams, "chap_perturb": AxpyParams,
     "chap_rand_uniform": RandParams, "chap_keep_mask": KeepMaskParams, "chap_chan_mask": ChanMaskParams,

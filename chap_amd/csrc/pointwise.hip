@@ -463,13 +463,17 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
     float s0[8], s1[8], mean[8], istd[8], k0[8], k1[8], k2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
-    if (P.bn) {
-        ld8(P.mean + c8, mean); ld8(P.invstd + c8, istd);
-        if (APPLY) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { k0[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; mean[j] = 0.f; istd[j] = 1.f; }
+    if (P.bn) { ld8(P.mean + c8, mean); ld8(P.invstd + c8, istd); }
+    if (APPLY) {
+        if (P.bn == 1) {                               // training-mode BatchNorm backward
             float gm[8], a0[8], a1[8];
             ld8(P.gamma + c8, gm); ld8(P.sums + c8, a0); ld8(P.sums + C + c8, a1);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { k0[j] = gm[j] * istd[j]; k1[j] = a0[j] / P.count; k2[j] = a1[j] / P.count; }
+        } else if (P.r.scale) {                        // fixed affine (eval-mode BN): dz/draw = scale
+            ld8(P.r.scale + c8, k0);
         }
     }
     if (prow < PPB) {
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
                 float o[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    o[j] = P.bn ? k0[j] * (dz[j] - k1[j] - (raw[j] - mean[j]) * istd[j] * k2[j]) : dz[j];
+                    o[j] = P.bn == 1 ? k0[j] * (dz[j] - k1[j] - (raw[j] - mean[j]) * istd[j] * k2[j]) : dz[j] * k0[j];
                 st8((T*)P.gout + pix * C + c8, o);
             }
         }
@@ -514,7 +518,8 @@ static int act_bwd_check(const chap_act_bwd_params* p) {
     CHAP_CHECK_ARG(p && p->r.ptr, "chap_act_bwd: null argument");
     CHAP_CHECK_ARG(p->r.C % 8 == 0 && 256 % (p->r.C / 8) == 0 && p->r.C <= 2048, "chap_act_bwd: C=%d unsupported", p->r.C);
     CHAP_CHECK_ARG(p->ng >= 0 && p->ng <= 3, "chap_act_bwd: ng=%d", p->ng);
-    CHAP_CHECK_ARG(!p->bn || (p->mean && p->invstd && p->gamma && p->sums), "chap_act_bwd: bn needs mean/invstd/gamma/sums");
+    CHAP_CHECK_ARG(p->bn >= 0 && p->bn <= 2, "chap_act_bwd: bn=%d", p->bn);
+    CHAP_CHECK_ARG(p->bn != 1 || (p->mean && p->invstd && p->gamma && p->sums), "chap_act_bwd: bn=1 needs mean/invstd/gamma/sums");
     CHAP_CHECK_ARG(!p->g_pool || (p->pool_idx && p->D == 1 && p->H % 2 == 0 && p->W % 2 == 0), "chap_act_bwd: pooled gradient needs idx and even 2D dims");
     return CHAP_OK;
 }
@@ -526,7 +531,7 @@ static int act_bwd_blocks(const chap_act_bwd_params* p) {
 }
 extern "C" int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream) {
     int r = act_bwd_check(p); if (r) return r;
-    CHAP_CHECK_ARG(p->bn, "chap_act_bwd_reduce: only needed with bn");
+    CHAP_CHECK_ARG(p->bn && p->mean && p->invstd && p->sums, "chap_act_bwd_reduce: needs bn, mean, invstd, sums");
     const size_t lds = 2 * p->r.C * sizeof(float);
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, false>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL((act_bwd_kernel<float, false>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
@@ -550,16 +555,18 @@ extern "C" int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream) {
 // Layout converters at the module boundary.
 template <typename T>
 __global__ void planar_to_cl_kernel(const chap_planar_to_cl_params P) {
-    const long total = (long)P.N * P.P * P.C;
+    const int Cp = P.Cpad > P.C ? P.Cpad : P.C;       // channels [C, Cpad) are written as zeros
+    const long total = (long)P.N * P.P * Cp;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % P.C); long r = i / P.C;
+        const int c = (int)(i % Cp); long r = i / Cp;
         const long pp = r % P.P; const int n = (int)(r / P.P);
-        ((T*)P.out)[(n * (long)P.P + pp) * P.out_ld + P.out_coff + c] = elem<T>::put(P.in[((long)n * P.C + c) * P.P + pp]);
+        const float v = c < P.C ? P.in[((long)n * P.C + c) * P.P + pp] : 0.f;
+        ((T*)P.out)[(n * (long)P.P + pp) * P.out_ld + P.out_coff + c] = elem<T>::put(v);
     }
 }
 extern "C" int chap_planar_to_cl(const chap_planar_to_cl_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->in && p->out, "chap_planar_to_cl: null argument");
-    const long total = (long)p->N * p->P * p->C;
+    const long total = (long)p->N * p->P * (p->Cpad > p->C ? p->Cpad : p->C);
     const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(planar_to_cl_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(planar_to_cl_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
@@ -584,5 +591,41 @@ extern "C" int chap_cl_to_planar(const chap_cl_to_planar_params* p, void* stream
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(cl_to_planar_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(cl_to_planar_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_cl_to_planar");
+    return CHAP_OK;
+}
+
+// =========================================================================================
+// out[c] += sum over pixels of a (lazy) channel-last tensor: bias gradient of layers whose output
+// gradient is not the B operand of chap_wgrad (transposed conv).
+template <typename T>
+__global__ __launch_bounds__(256) void channel_sum_kernel(const chap_chansum_params P) {
+    extern __shared__ float red[];
+    const int C = P.r.C, C8 = C / 8;
+    const int c8 = (threadIdx.x % C8) * 8, prow = threadIdx.x / C8, PPB = 256 / C8;
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = 0.f;
+    for (long pix = (long)blockIdx.x * PPB + prow; pix < P.npix; pix += (long)gridDim.x * PPB) {
+        float v[8];
+        src_load8<T>(P.r, (int)(pix / P.pix_per_sample), pix, c8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += v[j];
+    }
+    for (int i = threadIdx.x; i < C; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&red[c8 + j], s[j]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&P.out[i], red[i]);
+}
+extern "C" int chap_channel_sum(const chap_chansum_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->r.ptr && p->out && p->r.C % 8 == 0 && 256 % (p->r.C / 8) == 0, "chap_channel_sum: bad argument");
+    const int ppb = 256 / (p->r.C / 8);
+    long b = (p->npix + ppb - 1) / ppb;
+    const int nb = (int)(b < 512 ? b : 512);
+    const size_t lds = p->r.C * sizeof(float);
+    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(nb), dim3(256), lds, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nb), dim3(256), lds, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_channel_sum");
     return CHAP_OK;
 }

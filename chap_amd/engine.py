@@ -1,0 +1,367 @@
+"""Static-graph executor for the CHAP networks: hand-scheduled forward and backward passes made
+only of libchap_hip.so kernel launches (no torch compute ops, no autograd inside).
+
+A network is a `Program`: an ordered list of ops over named values.  A value is a *lazy
+activation* (ops.Lazy): the raw conv output plus the BatchNorm affine / LeakyReLU / dropout that
+its consumers apply while loading it.  The backward pass walks the program in reverse, keeping for
+every value the list of gradient contributions w.r.t. its ACTIVATED form; `chap_act_bwd_*` turns
+them into the gradient w.r.t. the raw tensor (BatchNorm backward fused), `chap_wgrad` and
+`chap_conv_fwd` (with *_DGRAD packings) do the rest.  Parameter gradients are accumulated straight
+into the model's flat gradient buffer.
+
+Reference semantics followed: code/networks/unet.py:44-292, code/networks/vnet.py:8-238.
+"""
+import torch
+
+from . import _lib as L
+from . import ops
+from .ops import Lazy
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+STATS_REPS = 8          # replicas of the BN statistics accumulators (spreads float atomics)
+
+
+class Op:
+    """kind: 'c1' | 'conv' | 'down' | 'deconv' | 'pool' | 'up'."""
+
+    def __init__(self, kind, out, srcs, **kw):
+        self.kind, self.out, self.srcs = kind, out, list(srcs)
+        self.w = kw.get("w")              # weight key (state dict)
+        self.b = kw.get("b")              # bias key
+        self.bn = kw.get("bn")            # BatchNorm prefix or None
+        self.ksize = kw.get("ksize", 3)
+        self.cin = kw.get("cin")
+        self.cout = kw.get("cout")
+        self.combine = kw.get("combine", 0)
+        self.slope = kw.get("slope", 0.0)  # activation after BN (when bn is set)
+        self.head = kw.get("head", False)  # planar fp32 logits
+        self.drop = kw.get("drop")         # (site, p, 'elem' | 'chan') applied to the OUTPUT value
+
+
+class Program:
+    def __init__(self, dims, ops_, heads, in_name="x"):
+        self.dims, self.ops, self.heads, self.in_name = dims, ops_, heads, in_name
+        self.consumers = {}
+        for op in ops_:
+            for s in op.srcs:
+                self.consumers.setdefault(s, []).append(op)
+
+
+def _taps(op, dims):
+    if op.kind in ("down", "deconv"):
+        return 2 ** dims
+    return op.ksize ** dims
+
+
+class Saved:
+    """What one forward pass leaves behind for its backward pass."""
+
+    def __init__(self):
+        self.vals = {}       # name -> Lazy
+        self.dims = {}       # name -> (D, H, W)
+        self.bnstat = {}     # bn prefix -> (mean, invstd, count)
+        self.pool_idx = {}   # pooled value name -> idx tensor
+        self.x = None
+        self.train = False
+
+
+class Executor:
+    """Runs a Program for one nn.Module (which owns parameters, buffers and the flat grad buffer)."""
+
+    def __init__(self, module, program):
+        self.m, self.prog = module, program
+        self._packed = {}          # (key, kind, dtype) -> packed weights
+        self._packed_version = None
+
+    # ---------------------------------------------------------------- parameters
+    def _sd(self):
+        return self.m._tensors()   # name -> tensor (params and buffers, fp32, on device)
+
+    def _pack(self, op, kind, dtype, sd):
+        ver = self.m._params_version()
+        if ver != self._packed_version:
+            self._packed.clear()
+            self._packed_version = ver
+        key = (op.w, kind, dtype)
+        t = self._packed.get(key)
+        if t is None:
+            w = sd[op.w]
+            if op.kind == "deconv":
+                cin, cout = w.shape[0], w.shape[1]
+            else:
+                cout, cin = w.shape[0], w.shape[1]
+            t = ops.pack_weights(w, kind, dtype, cin, cout, _taps(op, self.prog.dims))
+            self._packed[key] = t
+        return t
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, x, *, train, dtype, save, update_stats=True, drop_masks=None, rng=None):
+        """x: fp32 [N, 1, *spatial] contiguous. Returns (list of planar fp32 logits, Saved|None)."""
+        prog, sd, dims = self.prog, self._sd(), self.prog.dims
+        dev = x.device
+        N = x.shape[0]
+        sp = tuple(x.shape[2:])
+        D, H, W = ((1,) + sp) if dims == 2 else sp
+        S = Saved()
+        S.train, S.x = train, x
+        vals, vdims = S.vals, S.dims
+        vdims[prog.in_name] = (D, H, W)
+        # one zeroed fp32 arena for all BN statistics / affines of this pass
+        nbn = sum(op.cout for op in prog.ops if op.bn)
+        arena = torch.zeros(nbn * (2 * STATS_REPS + 4), dtype=torch.float32, device=dev)
+        apos = 0
+
+        def take(n):
+            nonlocal apos
+            t = arena[apos:apos + n]
+            apos += n
+            return t
+
+        outs = {}
+        for op in prog.ops:
+            k = op.kind
+            if k == "pool":
+                src = vals[op.srcs[0]]
+                d, h, w = vdims[op.srcs[0]]
+                out = torch.empty(N, 1, h // 2, w // 2, src.C, dtype=dtype, device=dev)
+                idx = torch.empty(N, 1, h // 2, w // 2, src.C, dtype=torch.uint8, device=dev) if save else None
+                ops.act_pool2(src, out, idx)
+                vals[op.out], vdims[op.out] = Lazy(out), (1, h // 2, w // 2)
+                if save:
+                    S.pool_idx[op.out] = idx
+                continue
+            if k == "up":
+                src = vals[op.srcs[0]]
+                d, h, w = vdims[op.srcs[0]]
+                od = 2 * d if dims == 3 else d
+                out = torch.empty(N, od, 2 * h, 2 * w, src.C, dtype=dtype, device=dev)
+                ops.upsample2x(src, out, dims=dims)
+                vals[op.out], vdims[op.out] = Lazy(out), (od, 2 * h, 2 * w)
+                continue
+            # ---- convolutions
+            stats = take(STATS_REPS * 2 * op.cout) if (op.bn and train) else None
+            bias = sd[op.b] if op.b else None
+            if k == "c1":
+                gd = (D, H, W)
+                out = torch.empty(N, D, H, W, op.cout, dtype=dtype, device=dev)
+                ops.conv_c1_fwd(x.view(N, D, H, W), sd[op.w], bias, out, dims=dims, stats=stats, stats_reps=STATS_REPS)
+            else:
+                srcs = [vals[s] for s in op.srcs]
+                sd_, sh_, sw_ = vdims[op.srcs[0]]
+                if k == "conv":
+                    gd, ind, ks, st, kind = (sd_, sh_, sw_), (sd_, sh_, sw_), op.ksize, 1, L.PACK_CONV_FWD
+                elif k == "down":
+                    gd = ((sd_ // 2) if dims == 3 else sd_, sh_ // 2, sw_ // 2)
+                    ind, ks, st, kind = (sd_, sh_, sw_), 2, 2, L.PACK_CONV_FWD
+                else:  # deconv == 1x1 conv + depth-to-space
+                    gd, ind, ks, st, kind = (sd_, sh_, sw_), (sd_, sh_, sw_), 1, 1, L.PACK_DECONV_FWD
+                wp = self._pack(op, kind, dtype, sd)
+                if op.head:
+                    out = torch.empty((N, op.cout) + ((gd[1], gd[2]) if dims == 2 else gd), dtype=torch.float32, device=dev)
+                    ops.conv_fwd(srcs, wp, bias, op.cout, out, grid=(N,) + gd, in_dims=ind, ksize=ks, stride=st, dims=dims,
+                                 combine=op.combine, out_planar=True, out_f32=True)
+                    outs[op.out] = out
+                    vdims[op.out] = gd
+                    continue
+                if k == "deconv":
+                    od = (2 * gd[0] if dims == 3 else gd[0], 2 * gd[1], 2 * gd[2])
+                    out = torch.empty((N,) + od + (op.cout,), dtype=dtype, device=dev)
+                    ops.conv_fwd(srcs, wp, bias, (2 ** dims) * op.cout, out, grid=(N,) + gd, in_dims=ind, ksize=1, stride=1, dims=dims,
+                                 combine=op.combine, out_mode=1, out_cn=op.cout, stats=stats, stats_reps=STATS_REPS)
+                    gd = od
+                else:
+                    out = torch.empty((N,) + gd + (op.cout,), dtype=dtype, device=dev)
+                    ops.conv_fwd(srcs, wp, bias, op.cout, out, grid=(N,) + gd, in_dims=ind, ksize=ks, stride=st, dims=dims,
+                                 combine=op.combine, stats=stats, stats_reps=STATS_REPS)
+            vdims[op.out] = gd
+            if op.bn:
+                scale, shift = take(op.cout), take(op.cout)
+                if train:
+                    mean, invstd = take(op.cout), take(op.cout)
+                    cnt = N * gd[0] * gd[1] * gd[2]
+                    upd = update_stats
+                    ops.bn_finalize(stats, STATS_REPS, sd[op.bn + ".weight"], sd[op.bn + ".bias"],
+                                    sd[op.bn + ".running_mean"] if upd else None, sd[op.bn + ".running_var"] if upd else None,
+                                    sd.get(op.bn + ".num_batches_tracked") if upd else None,
+                                    cnt, BN_EPS, BN_MOMENTUM if upd else 0.0, scale, shift, mean, invstd)
+                    S.bnstat[op.bn] = (mean, invstd, cnt)
+                else:
+                    ops.bn_eval_affine(sd[op.bn + ".weight"], sd[op.bn + ".bias"], sd[op.bn + ".running_mean"], sd[op.bn + ".running_var"],
+                                       BN_EPS, scale, shift)
+                lz = Lazy(out, scale, shift, True, op.slope)
+            else:
+                lz = Lazy(out)
+            if op.drop and train:
+                site, p, mode = op.drop
+                if mode == "elem":
+                    if drop_masks is not None:
+                        keep = drop_masks.get(site)
+                    else:
+                        keep = torch.empty(out.shape, dtype=torch.uint8, device=dev)
+                        ops.keep_mask(keep, rng.next_seed(), p, seed_dev=rng.seed_dev)
+                    if keep is not None:
+                        lz.keep, lz.keep_scale = keep, 1.0 / (1.0 - p)
+                else:
+                    if drop_masks is not None:
+                        cm = drop_masks.get(site)
+                    else:
+                        cm = torch.empty(N, op.cout, dtype=torch.float32, device=dev)
+                        ops.chan_mask(cm, rng.next_seed(), p, seed_dev=rng.seed_dev)
+                    if cm is not None:
+                        lz.chan_mul = cm
+            vals[op.out] = lz
+        logits = [outs[h] for h in prog.heads]
+        return logits, (S if save else None)
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, S, dlogits, *, dtype, need_wgrad, need_dx):
+        """dlogits: list (per head) of planar fp32 gradients or None. Accumulates parameter gradients
+        into the module's flat grad views; returns dx (fp32, shape of x) or None."""
+        prog, sd, dims = self.prog, self._sd(), self.prog.dims
+        gr = self.m._grad_views() if need_wgrad else None
+        dev = S.x.device
+        N = S.x.shape[0]
+        contrib = {}        # value name -> list of (tensor, coff)
+        pooled = {}         # value name -> (grad tensor, idx)
+        head_g = dict(zip(prog.heads, dlogits))
+        dx = None
+        nsub = 2 ** dims
+
+        for op in reversed(prog.ops):
+            k = op.kind
+            if k == "pool":
+                c = contrib.get(op.out)
+                if c:
+                    assert len(c) == 1 and c[0][1] == 0
+                    pooled[op.srcs[0]] = (c[0][0], S.pool_idx[op.out])
+                continue
+            if k == "up":
+                c = contrib.get(op.out)
+                if c:
+                    assert len(c) == 1
+                    src = S.vals[op.srcs[0]]
+                    d, h, w = S.dims[op.srcs[0]]
+                    o = torch.empty(N, d, h, w, src.C, dtype=dtype, device=dev)
+                    ops.upsample2x_bwd(c[0][0], c[0][1], src.C, o, dims=dims)
+                    contrib.setdefault(op.srcs[0], []).append((o, 0))
+                continue
+            # ---- gradient w.r.t. the raw output of this conv
+            if op.head:
+                dl = head_g.get(op.out)
+                if dl is None:
+                    continue
+                gd = S.dims[op.out]
+                g16 = torch.empty((N,) + gd + (16,), dtype=dtype, device=dev)
+                ops.planar_to_cl(dl, g16, cpad=16)
+                g = Lazy(g16)
+                kn_valid = op.cout
+            else:
+                c = contrib.get(op.out)
+                pl = pooled.get(op.out)
+                if not c and pl is None:
+                    continue
+                v = S.vals[op.out]
+                gd = S.dims[op.out]
+                kn_valid = 0
+                plain = (v.scale is None and not v.act and v.keep is None and v.chan_mul is None)
+                if plain and pl is None and len(c) == 1:
+                    g = Lazy(c[0][0], C=v.C, coff=c[0][1])
+                else:
+                    gout = torch.empty((N,) + gd + (v.C,), dtype=dtype, device=dev)
+                    kw = {}
+                    if op.bn:
+                        if S.train:
+                            mean, invstd, cnt = S.bnstat[op.bn]
+                            kw = dict(mean=mean, invstd=invstd, gamma=sd[op.bn + ".weight"], count=cnt, bn_mode=1)
+                        else:
+                            # eval-mode BN: fixed affine; BN parameter gradients from the same reduction
+                            rm, rv = sd[op.bn + ".running_mean"], sd[op.bn + ".running_var"]
+                            kw = dict(bn_mode=2)
+                            if need_wgrad:
+                                istd = self.m._eval_invstd(op.bn, rv)
+                                kw.update(mean=rm, invstd=istd, gamma=sd[op.bn + ".weight"])
+                        if need_wgrad:
+                            kw.update(dgamma=gr[op.bn + ".weight"], dbeta=gr[op.bn + ".bias"])
+                    ops.act_bwd(v, c or [], gout, g_pool=pl[0] if pl else None, pool_idx=pl[1] if pl else None, **kw)
+                    g = Lazy(gout)
+            # ---- this conv's own backward
+            if k == "c1":
+                D, H, W = S.dims[op.out]
+                gt = g.raw if (g.coff == 0 and g.C == g.ld) else None
+                assert gt is not None
+                if need_dx:
+                    dx = torch.empty_like(S.x)
+                ops.conv_c1_bwd(gt, sd[op.w], S.x.view(N, D, H, W), dims=dims,
+                                dx=dx.view(N, D, H, W) if need_dx else None,
+                                dw=gr[op.w] if need_wgrad else None, db=gr[op.b] if (need_wgrad and op.b) else None)
+                continue
+            srcs = [S.vals[s] for s in op.srcs]
+            sd_, sh_, sw_ = S.dims[op.srcs[0]]
+            ctot = sum(s.C for s in srcs) if op.combine == 0 else srcs[0].C
+            if k == "conv":
+                taps = op.ksize ** dims
+                if need_wgrad:
+                    ops.wgrad(srcs, g, gr[op.w], (1, taps, ctot * taps), grid=(N, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
+                              ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid)
+                if self._needs_src_grad(op, need_dx):
+                    wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
+                    dsrc = torch.empty(N, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                    ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(N, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
+                    self._scatter(contrib, op, srcs, dsrc)
+            elif k == "down":
+                gdd = S.dims[op.out]
+                if need_wgrad:
+                    ops.wgrad(srcs, g, gr[op.w], (1, nsub, ctot * nsub), grid=(N,) + gdd, in_dims=(sd_, sh_, sw_),
+                              ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None)
+                if self._needs_src_grad(op, need_dx):
+                    wp = self._pack(op, L.PACK_DOWN_DGRAD, dtype, sd)
+                    dsrc = torch.empty(N, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                    ops.conv_fwd([g], wp, None, nsub * ctot, dsrc, grid=(N,) + gdd, in_dims=gdd, ksize=1, stride=1, dims=dims,
+                                 out_mode=1, out_cn=ctot)
+                    self._scatter(contrib, op, srcs, dsrc)
+            else:  # deconv: A = fine gradient (kc = co), B = coarse input (kn = ci)
+                fine = S.dims[op.out]
+                if need_wgrad:
+                    assert len(srcs) == 1
+                    ops.wgrad([g], srcs[0], gr[op.w], (1, nsub, op.cout * nsub), grid=(N, sd_, sh_, sw_), in_dims=fine,
+                              ksize=2, stride=2, dims=dims)
+                    if op.b:
+                        ops.channel_sum(g, gr[op.b])
+                if self._needs_src_grad(op, need_dx):
+                    wp = self._pack(op, L.PACK_DECONV_DGRAD, dtype, sd)
+                    dsrc = torch.empty(N, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                    ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(N, sd_, sh_, sw_), in_dims=fine, ksize=2, stride=2, dims=dims)
+                    self._scatter(contrib, op, srcs, dsrc)
+        return dx
+
+    def _needs_src_grad(self, op, need_dx):
+        return True          # every non-first conv feeds back into earlier layers (BN params / dx)
+
+    @staticmethod
+    def _scatter(contrib, op, srcs, dsrc):
+        if op.combine == 0:
+            off = 0
+            for name, s in zip(op.srcs, srcs):
+                contrib.setdefault(name, []).append((dsrc, off))
+                off += s.C
+        else:
+            for name in op.srcs:
+                contrib.setdefault(name, []).append((dsrc, 0))
+
+
+class Rng:
+    """Seeds for the in-kernel counter RNG: a host counter (distinct stream per call site) plus an
+    optional device word that the host bumps between replays of a captured graph."""
+
+    def __init__(self, seed, device):
+        self.base = int(seed) & 0xFFFFFFFF
+        self.count = 0
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def next_seed(self):
+        self.count += 1
+        return (self.base << 20) + self.count
+
+    def reset_counter(self):
+        self.count = 0

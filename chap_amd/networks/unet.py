@@ -1,0 +1,131 @@
+"""2D networks with the reference's module interface (code/networks/unet.py): same class names,
+constructor/forward signatures, attribute tree and state-dict keys -- the forward/backward are one
+hand-scheduled HIP program (chap_amd.engine), not torch.nn calls.
+
+    ConvBlock   unet.py:44-60     Conv3x3+b -> BN -> LeakyReLU -> Dropout(p) -> Conv3x3+b -> BN -> LeakyReLU
+    DownBlock   unet.py:63-75     MaxPool2d(2) -> ConvBlock
+    UpBlock     unet.py:78-99     [Conv1x1 -> bilinear x2 (align_corners)] | ConvTranspose2d k2 s2 ; cat ; ConvBlock
+    Encoder     unet.py:125-151   Decoder unet.py:153-190   DualDecoder unet.py:245-292   UNet unet.py:498-552
+"""
+import torch.nn as nn
+
+from ..engine import Op, Program
+from .base import ChapNet, holder
+
+FT = (16, 32, 64, 128, 256)
+DROP = (0.05, 0.1, 0.2, 0.3, 0.5)
+SLOPE = 0.01
+
+
+def _conv_block(cin, cout):
+    # children "0","1","4","5" = conv, bn, conv, bn (2, 3, 6 are activation / dropout: no state)
+    return holder(conv_conv=holder(_0=nn.Conv2d(cin, cout, 3, padding=1), _1=nn.BatchNorm2d(cout),
+                                   _4=nn.Conv2d(cout, cout, 3, padding=1), _5=nn.BatchNorm2d(cout)))
+
+
+def _encoder(in_chns):
+    enc = holder(in_conv=_conv_block(in_chns, FT[0]))
+    for i in range(1, 5):
+        enc.add_module("down%d" % i, holder(maxpool_conv=holder(_1=_conv_block(FT[i - 1], FT[i]))))
+    return enc
+
+
+def _decoder(n_class, bilinear):
+    dec = nn.Module()
+    for k in range(1, 5):
+        c1, c2 = FT[5 - k], FT[4 - k]
+        up = nn.Module()
+        if bilinear:
+            up.add_module("conv1x1", nn.Conv2d(c1, c2, 1))
+        else:
+            up.add_module("up", nn.ConvTranspose2d(c1, c2, 2, stride=2))
+        up.add_module("conv", _conv_block(2 * c2, c2))
+        dec.add_module("up%d" % k, up)
+    dec.add_module("out_conv", nn.Conv2d(FT[0], n_class, 3, padding=1))
+    return dec
+
+
+def _block_ops(ops, pre, src, out, cin, cout, drop_p, first=False):
+    mid = out + ".a"
+    kw = dict(w=pre + ".0.weight", b=pre + ".0.bias", bn=pre + ".1", slope=SLOPE, cin=cin, cout=cout,
+              drop=(pre, drop_p, "elem") if drop_p > 0 else None)
+    if first:
+        ops.append(Op("c1", mid, [], **kw))
+    else:
+        ops.append(Op("conv", mid, src, ksize=3, **kw))
+    ops.append(Op("conv", out, [mid], ksize=3, w=pre + ".4.weight", b=pre + ".4.bias", bn=pre + ".5", slope=SLOPE, cin=cout, cout=cout))
+
+
+def build_program(n_class, decoders, enc_root="encoder"):
+    """decoders: list of (root name, bilinear?)."""
+    ops = []
+    _block_ops(ops, enc_root + ".in_conv.conv_conv", None, "e0", 1, FT[0], DROP[0], first=True)
+    for i in range(1, 5):
+        ops.append(Op("pool", "p%d" % i, ["e%d" % (i - 1)]))
+        _block_ops(ops, "%s.down%d.maxpool_conv.1.conv_conv" % (enc_root, i), ["p%d" % i], "e%d" % i, FT[i - 1], FT[i], DROP[i])
+    heads = []
+    for root, bilinear in decoders:
+        x = "e4"
+        for k in range(1, 5):
+            c1, c2 = FT[5 - k], FT[4 - k]
+            up = "%s.up%d" % (root, k)
+            u = "%s.u%d" % (root, k)
+            if bilinear:
+                ops.append(Op("conv", u + ".lo", [x], ksize=1, w=up + ".conv1x1.weight", b=up + ".conv1x1.bias", cin=c1, cout=c2))
+                ops.append(Op("up", u, [u + ".lo"]))
+            else:
+                ops.append(Op("deconv", u, [x], w=up + ".up.weight", b=up + ".up.bias", cin=c1, cout=c2))
+            d = "%s.d%d" % (root, k)
+            _block_ops(ops, up + ".conv.conv_conv", ["e%d" % (4 - k), u], d, 2 * c2, c2, 0.0)
+            x = d
+        ops.append(Op("conv", root + ".logits", [x], ksize=3, w=root + ".out_conv.weight", b=root + ".out_conv.bias",
+                      cin=FT[0], cout=n_class, head=True))
+        heads.append(root + ".logits")
+    return Program(2, ops, heads)
+
+
+class DualDecoder(ChapNet):
+    """forward(x, with_feat=False, dropout=False, dropout_level=None, scores=None, comp_dropout=False)
+    -> (out1, out2[, features])   -- unet.py:277-292.  decoder1 = bilinear, decoder2 per decoder_type."""
+
+    dims = 2
+
+    def __init__(self, in_chns, class_num, args):
+        super().__init__()
+        if in_chns != 1:
+            raise NotImplementedError("chap_amd: in_chns=%d (the CHAP hot path is single-channel)" % in_chns)
+        self.decoder_type = args["decoder_type"]
+        if self.decoder_type not in ("mcnet", "same"):
+            raise NotImplementedError("chap_amd: decoder_type=%r (mcnet/same built)" % self.decoder_type)
+        self.encoder = _encoder(in_chns)
+        self.decoder1 = _decoder(class_num, True)
+        self.decoder2 = _decoder(class_num, self.decoder_type == "same")
+        self._finish_init(build_program(class_num, [("decoder1", True), ("decoder2", self.decoder_type == "same")]))
+
+    def forward(self, x, with_feat=False, dropout=False, dropout_level=None, scores=None, comp_dropout=False,
+                drop_masks=None, update_stats=True):
+        if dropout:
+            raise NotImplementedError("chap_amd: channel-dropout branch (perform_dropout) is a next-row item, see DESIGN.md")
+        out = self._run(x, drop_masks=drop_masks, update_stats=update_stats)
+        if with_feat:
+            raise NotImplementedError("chap_amd: with_feat=True is not built yet")
+        return out[0], out[1]
+
+
+class UNet(ChapNet):
+    """forward(x, with_feats=False) -> logits   -- unet.py:498-521 (net_type='unet')."""
+
+    dims = 2
+
+    def __init__(self, in_chns, class_num):
+        super().__init__()
+        if in_chns != 1:
+            raise NotImplementedError("chap_amd: in_chns=%d" % in_chns)
+        self.encoder = _encoder(in_chns)
+        self.decoder = _decoder(class_num, True)
+        self._finish_init(build_program(class_num, [("decoder", True)]))
+
+    def forward(self, x, with_feats=False, drop_masks=None, update_stats=True):
+        if with_feats:
+            raise NotImplementedError("chap_amd: with_feats=True is not built yet")
+        return self._run(x, drop_masks=drop_masks, update_stats=update_stats)[0]

@@ -187,23 +187,36 @@ def _act_bwd_params(lazy, grads, g_pool, pool_idx, mean, invstd, gamma, sums, go
 
 
 def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=None, gamma=None,
-            dgamma=None, dbeta=None, count=1.0):
-    """grads: list of (tensor, channel offset). With mean/invstd/gamma -> BN backward fused in."""
-    sums = None
-    if mean is not None:
+            dgamma=None, dbeta=None, count=1.0, bn_mode=None, sums=None):
+    """grads: list of (tensor, channel offset).
+    bn_mode 1 (default when mean is given): training-mode BN backward fused in;
+    bn_mode 2: fixed affine (eval-mode BN), dgamma/dbeta from the same reduction when requested."""
+    if bn_mode is None:
+        bn_mode = 1 if mean is not None else 0
+    need_reduce = bn_mode == 1 or (bn_mode == 2 and (dgamma is not None or dbeta is not None))
+    if need_reduce and sums is None:
         sums = torch.zeros(2 * lazy.C, dtype=torch.float32, device=gout.device)
     p = _act_bwd_params(lazy, grads, g_pool, pool_idx, mean, invstd, gamma, sums, gout, dgamma, dbeta, count)
-    if mean is not None:
+    p.bn = bn_mode
+    if need_reduce:
         L.call("chap_act_bwd_reduce", p, _stream())
     L.call("chap_act_bwd_apply", p, _stream())
 
 
-def planar_to_cl(x, out, out_coff=0):
-    """fp32 [N, C, *spatial] -> out [N, D, H, W, ld] (dtype of out)."""
+def channel_sum(lazy, out):
+    p = L.ChanSumParams()
+    lazy.fill(p.r)
+    n = lazy.raw.shape[0]
+    p.out, p.npix, p.pix_per_sample, p.dtype = out.data_ptr(), lazy.raw[..., 0].numel(), lazy.raw[0, ..., 0].numel(), dt(lazy.raw)
+    L.call("chap_channel_sum", p, _stream())
+
+
+def planar_to_cl(x, out, out_coff=0, cpad=0):
+    """fp32 [N, C, *spatial] -> out [N, D, H, W, ld] (dtype of out); channels [C, cpad) zero-filled."""
     p = L.PlanarToClParams()
     N, Cc = x.shape[0], x.shape[1]
     p.in_, p.out, p.N, p.C, p.P = x.data_ptr(), out.data_ptr(), N, Cc, x[0, 0].numel()
-    p.out_ld, p.out_coff, p.dtype = out.shape[-1], out_coff, dt(out)
+    p.out_ld, p.out_coff, p.Cpad, p.dtype = out.shape[-1], out_coff, cpad, dt(out)
     L.call("chap_planar_to_cl", p, _stream())
 
 

@@ -195,7 +195,8 @@ typedef struct {
     float* sums;            /* [2][C] workspace, zeroed by the caller                             */
     void*  gout;            /* [pixels][C] dtype                                                  */
     float* dgamma; float* dbeta;                     /* accumulated (+=)                          */
-    int32_t N, D, H, W;  int32_t bn;  float count;  int32_t dtype;
+    int32_t N, D, H, W;  int32_t bn;  /* 0 none, 1 training-mode BN, 2 fixed affine (eval BN): g = dz*scale */
+    float count;  int32_t dtype;
 } chap_act_bwd_params;
 int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream);
 int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream);
@@ -219,10 +220,13 @@ typedef struct {
 int chap_upsample2x_bwd(const chap_upsample_bwd_params* p, void* stream);
 
 /* Layout / dtype helpers at the module boundary. */
-typedef struct { const float* in; void* out; int32_t N, C, P, out_ld, out_coff, dtype; } chap_planar_to_cl_params;
+typedef struct { const float* in; void* out; int32_t N, C, P, out_ld, out_coff, Cpad, dtype; } chap_planar_to_cl_params;  /* channels [C,Cpad) zero-filled */
 int chap_planar_to_cl(const chap_planar_to_cl_params* p, void* stream);  /* fp32 [N][C][P] -> dtype [N][P][C] */
 typedef struct { chap_src_t r; float* out; int32_t N, P; int32_t dtype; } chap_cl_to_planar_params;
 int chap_cl_to_planar(const chap_cl_to_planar_params* p, void* stream);  /* (lazy) [N][P][C] -> fp32 [N][C][P] */
+
+typedef struct { chap_src_t r; float* out; int64_t npix; int64_t pix_per_sample; int32_t dtype; } chap_chansum_params;
+int chap_channel_sum(const chap_chansum_params* p, void* stream);       /* out[c] += sum_pixels a[pixel][c] (fp32, atomics) */
 
 /* ------------------------------------------------------------------------------------------
  * Segmentation losses on fp32 planar logits [N][C][P]  (train_ours_2D.py:198-216, 319-325). */

@@ -1,0 +1,136 @@
+"""2D networks through the drop-in nn.Module boundary on the GPU against the golden fixtures
+(outputs of the imported reference) and the CPU oracle.  Tolerances: fp32 mode logits 1e-4 rel
+(north_star), gradients judged against the fp64 truth relative to the fp32 reference's own error;
+bf16 mode looser (stated below)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from chap_amd.networks import DualDecoder, UNet, net_factory
+from oracle import init as oinit
+from oracle import nets as onets
+
+DEV = "cuda"
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def relerr(a, b):
+    a = a.detach().double().cpu().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().double().cpu().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    if np.abs(b).max() < 1e-9:
+        return np.abs(a).max()
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def cl_masks(masks):
+    return {k: v.permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(DEV) for k, v in masks.items()}
+
+
+def run_case(model, x, cot_seed, **kw):
+    x = torch.from_numpy(x).to(DEV).requires_grad_(True)
+    outs = model(x, **kw)
+    outs = outs if isinstance(outs, tuple) else (outs,)
+    g = torch.Generator().manual_seed(cot_seed)
+    cots = [torch.randn(o.shape, generator=g).to(DEV) for o in outs]
+    model.zero_grad()
+    torch.autograd.backward(outs, cots)
+    return outs, x.grad
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dualdecoder_eval(golden_dir, dtype):
+    g = _load(golden_dir, "dualdecoder2d_64.npz")
+    m = net_factory("dualdecoder", 1, 4, DEV, {"decoder_type": "mcnet"})
+    m.load_state_dict(oinit.dual_decoder_2d_state(int(g["state_seed"])), strict=True)
+    m.set_compute_dtype(dtype).eval()
+    outs, dx = run_case(m, g["x"], int(g["cot_seed"]))
+    tol = 1e-4 if dtype == torch.float32 else 4e-2
+    assert relerr(outs[0], g["eval_logits0"]) < tol
+    assert relerr(outs[1], g["eval_logits1"]) < tol
+    gt = 2e-3 if dtype == torch.float32 else 8e-2
+    assert relerr(dx, g["eval_dx"]) < gt
+    grads = dict(m.named_parameters())
+    for i, n in enumerate(g["grad_pick_names"]):
+        assert relerr(grads[str(n)].grad, g["eval_grad_pick%d" % i]) < gt, n
+    names = [str(n) for n in g["param_names"]]
+    got = np.array([float(grads[n].grad.double().abs().sum()) for n in names])
+    np.testing.assert_allclose(got, g["eval_grad_checks"][:, 1], rtol=5e-3 if dtype == torch.float32 else 1e-1, atol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dualdecoder_train_injected(golden_dir, dtype):
+    g = _load(golden_dir, "dualdecoder2d_64.npz")
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV)
+    m.load_state_dict(oinit.dual_decoder_2d_state(int(g["state_seed"])), strict=True)
+    m.set_compute_dtype(dtype).train()
+    x = g["x"]
+    masks = oinit.drop_masks_2d(int(g["mask_seed"]), x.shape[0], x.shape[2], x.shape[3])
+    outs, dx = run_case(m, x, int(g["cot_seed"]), drop_masks=cl_masks(masks))
+    tol = 1e-4 if dtype == torch.float32 else 5e-2
+    assert relerr(outs[0], g["train_logits0"]) < tol
+    assert relerr(outs[1], g["train_logits1"]) < tol
+    # gradients: distance to the fp64 truth, relative to the fp32 reference's own distance
+    ref_err = relerr(g["train_dx"], g["train64_dx"])
+    lim = max(4 * ref_err, 1e-3) if dtype == torch.float32 else 0.25
+    assert relerr(dx, g["train64_dx"]) < lim
+    grads = dict(m.named_parameters())
+    for i, n in enumerate(g["grad_pick_names"]):
+        ref_e = relerr(g["train_grad_pick%d" % i], g["train64_grad_pick%d" % i])
+        lim_i = max(4 * ref_e, 1e-3) if dtype == torch.float32 else 0.25
+        e = relerr(grads[str(n)].grad, g["train64_grad_pick%d" % i])
+        if np.abs(g["train64_grad_pick%d" % i]).max() < 1e-9:      # conv bias before train-mode BN: exactly 0
+            assert e < (1e-3 if dtype == torch.float32 else 0.5), n
+        else:
+            assert e < lim_i, (n, e, lim_i)
+    sd = m.state_dict()
+    rt = 1e-4 if dtype == torch.float32 else 2e-2
+    for k in ("encoder.in_conv.conv_conv.1", "encoder.down3.maxpool_conv.1.conv_conv.5", "decoder2.up4.conv.conv_conv.1"):
+        assert relerr(sd[k + ".running_mean"], g["after_rm_" + k]) < rt
+        assert relerr(sd[k + ".running_var"], g["after_rv_" + k]) < rt
+    assert int(sd["encoder.in_conv.conv_conv.1.num_batches_tracked"]) == 1
+
+
+def test_dualdecoder_fullsize_and_unet(golden_dir):
+    g = _load(golden_dir, "dualdecoder2d_256.npz")
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).eval()
+    m.load_state_dict(oinit.dual_decoder_2d_state(int(g["state_seed"])), strict=True)
+    x = torch.rand(1, 1, 256, 256, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV)
+    with torch.no_grad():
+        o1, o2 = m(x)
+    assert relerr(o1[:, :, ::4, ::4], g["logits0_sub"]) < 1e-4
+    assert relerr(o2[:, :, ::4, ::4], g["logits1_sub"]) < 1e-4
+    g = _load(golden_dir, "unet2d_32.npz")
+    u = net_factory("unet", 1, 4, DEV)
+    u.load_state_dict(oinit.unet_2d_state(int(g["state_seed"])), strict=True)
+    u.eval()
+    outs, dx = run_case(u, g["x"], int(g["cot_seed"]))
+    assert relerr(outs[0], g["eval_logits0"]) < 1e-4
+    assert relerr(dx, g["eval_dx"]) < 2e-3
+
+
+def test_train_mode_random_dropout_and_frozen():
+    """in-kernel RNG dropout: runs, is reproducible for a fixed seed state, and the frozen()
+    context yields dL/dx without touching parameter gradients."""
+    torch.manual_seed(3)
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train()
+    x = torch.rand(2, 1, 64, 64, device=DEV, requires_grad=True)
+    o1, o2 = m(x)
+    assert torch.isfinite(o1).all() and torch.isfinite(o2).all()
+    with m.frozen():
+        a, b = m(x, update_stats=False)
+        (a.sum() + b.sum()).backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and x.grad.abs().sum() > 0
+    assert all(p.grad is None or p.grad.abs().sum() == 0 for p in m.parameters())
+
+
+def test_cpu_module_fails_loudly():
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"})
+    with pytest.raises(Exception, match="no CPU fallback"):
+        m(torch.rand(1, 1, 32, 32))
