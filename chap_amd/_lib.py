@@ -153,7 +153,7 @@ class DiffMaskParams(C.Structure):
 
 
 class SgdParams(C.Structure):
-    _fields_ = [("param", _vp), ("grad", _vp), ("mom", _vp), ("lr", _vp), ("momentum", _f32), ("weight_decay", _f32),
+    _fields_ = [("param", _vp), ("grad", _vp), ("grad2", _vp), ("mom", _vp), ("lr", _vp), ("momentum", _f32), ("weight_decay", _f32),
                 ("grad_scale", _f32), ("n", _i64), ("zero_grad", _i32)]
 
 

@@ -188,17 +188,22 @@ __global__ void sgd_kernel(const chap_sgd_params P) {
     const long n4 = P.n / 4;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 p = ((float4*)P.param)[i], g = ((float4*)P.grad)[i], m = ((float4*)P.mom)[i];
+        if (P.grad2) { const float4 h = ((float4*)P.grad2)[i]; g.x += h.x; g.y += h.y; g.z += h.z; g.w += h.w; }
 #define CHAP_SGD1(f) { const float gg = g.f * P.grad_scale + P.weight_decay * p.f; m.f = P.momentum * m.f + gg; p.f -= lr * m.f; }
         CHAP_SGD1(x) CHAP_SGD1(y) CHAP_SGD1(z) CHAP_SGD1(w)
         ((float4*)P.param)[i] = p; ((float4*)P.mom)[i] = m;
-        if (P.zero_grad) ((float4*)P.grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.zero_grad) {
+            ((float4*)P.grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (P.grad2) ((float4*)P.grad2)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     if (blockIdx.x == 0) {
         for (long i = n4 * 4 + threadIdx.x; i < P.n; i += blockDim.x) {
-            const float gg = P.grad[i] * P.grad_scale + P.weight_decay * P.param[i];
+            const float gr = P.grad[i] + (P.grad2 ? P.grad2[i] : 0.f);
+            const float gg = gr * P.grad_scale + P.weight_decay * P.param[i];
             const float mm = P.momentum * P.mom[i] + gg;
             P.mom[i] = mm; P.param[i] -= lr * mm;
-            if (P.zero_grad) P.grad[i] = 0.f;
+            if (P.zero_grad) { P.grad[i] = 0.f; if (P.grad2) P.grad2[i] = 0.f; }
         }
     }
 }

@@ -347,8 +347,8 @@ def diff_mask(p1, p2, knowledge, scale, topk):
     return out
 
 
-def sgd_step(param, grad, mom, lr_dev, momentum, weight_decay, grad_scale=1.0, zero_grad=True):
+def sgd_step(param, grad, mom, lr_dev, momentum, weight_decay, grad_scale=1.0, zero_grad=True, grad2=None):
     p = L.SgdParams()
-    p.param, p.grad, p.mom, p.lr = param.data_ptr(), grad.data_ptr(), mom.data_ptr(), lr_dev.data_ptr()
+    p.param, p.grad, p.grad2, p.mom, p.lr = param.data_ptr(), grad.data_ptr(), _p(grad2), mom.data_ptr(), lr_dev.data_ptr()
     p.momentum, p.weight_decay, p.grad_scale, p.n, p.zero_grad = momentum, weight_decay, grad_scale, param.numel(), int(zero_grad)
     L.call("chap_sgd_step", p, _stream())

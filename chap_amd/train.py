@@ -1,0 +1,255 @@
+"""Host side of one CHAP training iteration, mirroring code/train_ours_2D.py:301-389 step by step
+(same names where the reference has them).  Every tensor op is a libchap_hip.so kernel; torch
+provides memory, streams, the autograd trampoline for the two network nodes and (optionally) HIP
+graph capture of the whole iteration.
+
+Pieces that are ABSENT from the reference (losses.VAT2d, patch.create_maskV1, losses.DiceLoss_bcp,
+ramps.sigmoid_rampup) follow the definitions in DESIGN.md (P1-P4); the CPU oracle restates the same
+definitions (oracle/train_step.py).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def sigmoid_rampup(current, rampup_length):
+    if rampup_length == 0:
+        return 1.0
+    t = float(np.clip(current, 0.0, rampup_length)) / rampup_length
+    return float(math.exp(-5.0 * (1.0 - t) ** 2))
+
+
+def get_current_consistency_weight(epoch, args):            # train_ours_2D.py:34-36
+    return args["consistency"] * sigmoid_rampup(epoch, args["consistency_rampup"])
+
+
+DEFAULT_ARGS = dict(base_lr=0.01, batch_size=24, labeled_bs=12, max_iterations=30000, num_classes=4,
+                    consistency=1.0, consistency_rampup=50.0, noise_mag=10.0, epi=6.0, topk1=0.1,
+                    adv_noise=True, adv_losstype="kl", vat_iters=1, vat_sign=False, nms=1,
+                    momentum=0.9, weight_decay=1e-4)
+
+
+class FusedSGD:
+    """optim.SGD(lr, momentum=0.9, weight_decay=1e-4) (train_ours_2D.py:278) as ONE kernel over the
+    model's flat parameter buffer; lr lives in device memory (graph replays pick up new values)."""
+
+    def __init__(self, model, lr, momentum=0.9, weight_decay=1e-4):
+        self.model, self.momentum, self.weight_decay = model, momentum, weight_decay
+        flat, grad = model.flat_buffers()
+        self.mom = torch.zeros_like(flat)
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=flat.device)
+        self.param_groups = [{"lr": float(lr)}]
+
+    def set_lr(self, lr):
+        self.param_groups[0]["lr"] = float(lr)
+        self.lr_dev.fill_(float(lr))
+
+    def zero_grad(self, set_to_none=False):
+        pass                                   # the step kernel zeroes the gradient buffer
+
+    def step(self, grad_scale=1.0, grad2=None):
+        flat, grad = self.model.flat_buffers()
+        ops.sgd_step(flat, grad, self.mom, self.lr_dev, self.momentum, self.weight_decay, grad_scale, True, grad2)
+        self.model.mark_params_dirty()
+
+
+class VAT2d:
+    """adv_loss = VAT2d(xi, epi, num_classes); adv_loss(model, x, soft1, soft2, mask, losstype)
+    (call sites train_ours_2D.py:290,372).  Returns a 1-element device tensor; the gradient of
+    `weight * loss` w.r.t. the parameters is accumulated into the model's gradient buffer here
+    (the network node is driven directly with d(loss)/d(logits) from the fused KL kernel)."""
+
+    def __init__(self, xi=10.0, epi=6.0, num_classes=4, ip=1, sign=False):
+        self.xi, self.epi, self.num_classes, self.ip, self.sign = xi, epi, num_classes, ip, sign
+
+    def __call__(self, model, x, soft1, soft2, mask, losstype="kl", weight_dev=None, inject=None, accumulate_grad=True):
+        if losstype != "kl":
+            raise NotImplementedError("chap_amd VAT2d: adv_losstype=%r (kl built)" % losstype)
+        inject = inject or {}
+        U = soft1.shape[0]
+        x = x[-U:].contiguous()                 # "perturb the last U samples" (SURVEY.md section 3.1 note)
+        d = torch.empty_like(x)
+        if inject.get("d0") is not None:
+            ops.l2_normalize(inject["d0"], d)
+        else:
+            ops.rand_uniform(d, model._rng.next_seed(), -0.5, 0.5, seed_dev=model._rng.seed_dev)
+            ops.l2_normalize(d, d)
+        xh = torch.empty_like(x).requires_grad_(True)
+        for it in range(self.ip):
+            ops.perturb(x, d, xh, self.xi)
+            with model.frozen():
+                l1, l2 = model(xh, update_stats=False, drop_masks=inject.get("drop_V%d" % it))
+            g1, g2 = torch.empty_like(l1), torch.empty_like(l2)
+            ops.kl_fwd_bwd((l1, l2), (soft1, soft2), None, (g1, g2))
+            xh.grad = None
+            torch.autograd.backward([l1, l2], [g1, g2])
+            ops.l2_normalize(xh.grad, d)
+        xa = torch.empty_like(x)
+        m = None if mask is None else mask.reshape(x.shape)
+        alpha = self.epi / math.sqrt(x[0].numel()) if self.sign else self.epi
+        ops.perturb(x, d, xa, alpha, mask=m, sign=self.sign)
+        loss = torch.zeros(1, dtype=torch.float32, device=x.device)
+        if accumulate_grad:
+            l1, l2 = model(xa, update_stats=False, drop_masks=inject.get("drop_VF"))
+            g1, g2 = torch.empty_like(l1), torch.empty_like(l2)
+            ops.kl_fwd_bwd((l1, l2), (soft1, soft2), loss, (g1, g2), gscale_dev=weight_dev)
+            torch.autograd.backward([l1, l2], [g1, g2])
+        else:
+            with torch.no_grad():
+                l1, l2 = model(xa, update_stats=False, drop_masks=inject.get("drop_VF"))
+            ops.kl_fwd_bwd((l1, l2), (soft1, soft2), loss)
+        return loss
+
+
+class ChapStep:
+    """One iteration of train() (train_ours_2D.py:301-389) for a DualDecoder on 2D slices.
+
+    step(volume_batch [B,1,H,W] fp32, label_batch [B,H,W] int64) -> dict of device scalars.
+    The BCP box offsets, LR and consistency weight live in device memory so that the whole iteration
+    can be captured once as a HIP graph (`capture()`) and replayed."""
+
+    def __init__(self, model, args=None, optimizer=None, world_size=1):
+        a = dict(DEFAULT_ARGS)
+        a.update(args or {})
+        self.args, self.model = a, model
+        self.opt = optimizer or FusedSGD(model, a["base_lr"], a["momentum"], a["weight_decay"])
+        self.adv_loss = VAT2d(xi=a["noise_mag"], epi=a["epi"], num_classes=a["num_classes"], ip=a["vat_iters"], sign=a["vat_sign"])
+        dev = self.opt.lr_dev.device
+        self.box = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.cw_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.iter_num = 0
+        self.world_size = world_size
+        self.grad_sync = None                   # set by parallel.DataParallelSync
+        self._graph = None
+
+    # ------------------------------------------------------------------ host-side schedule values
+    def prepare(self, box_yx=None):
+        """Host work of an iteration that must happen BEFORE the device work (and outside a captured
+        graph): BCP box offsets (np.random.randint, train_ours_2D.py:97-98), consistency weight."""
+        a = self.args
+        H, W = self._hw
+        ph, pw = int(H * 2 / 3), int(W * 2 / 3)
+        if box_yx is None:
+            box_yx = (np.random.randint(0, H - ph), np.random.randint(0, W - pw))
+        self.box.copy_(torch.tensor([box_yx[0], box_yx[1], ph, pw], dtype=torch.int32))
+        self.cw_dev.fill_(get_current_consistency_weight(self.iter_num // 150, a))
+
+    def finish(self):
+        """poly LR applied AFTER the step (train_ours_2D.py:385-389)."""
+        a = self.args
+        self.iter_num += 1
+        lr_ = a["base_lr"] * (1.0 - self.iter_num / a["max_iterations"]) ** 0.9
+        self.opt.set_lr(lr_)
+        return lr_
+
+    # ------------------------------------------------------------------ the device work
+    def device_step(self, volume_batch, label_batch, inject=None):
+        a, model = self.args, self.model
+        inject = inject or {}
+        nc = a["num_classes"]
+        lbs = a["labeled_bs"]
+        B = volume_batch.shape[0]
+        lsub, usub = lbs // 2, (B - lbs) // 2
+        img_a, img_b = volume_batch[:lsub], volume_batch[lsub:lbs]
+        uimg_a, uimg_b = volume_batch[lbs:lbs + usub], volume_batch[lbs + usub:]
+        lab_a, lab_b = label_batch[:lsub], label_batch[lsub:lbs]
+        uimg_ab = volume_batch[lbs:]
+
+        # ---- pass A: pseudo labels from both decoders (no grad), train_ours_2D.py:314-330
+        with torch.no_grad():
+            pre_ab1, pre_ab2 = model(uimg_ab, drop_masks=inject.get("drop_A"))
+            outputs_soft1, outputs_soft2, pseudo_outputs1, pseudo_outputs2, knowledge = ops.pseudo_block(pre_ab1, pre_ab2)
+            if a["nms"]:
+                plab1 = ops.largest_cc(pseudo_outputs1, nc)
+                plab2 = ops.largest_cc(pseudo_outputs2, nc)
+            else:
+                plab1, plab2 = pseudo_outputs1, pseudo_outputs2
+            plab_a1, plab_b1 = plab1[:usub], plab1[usub:]
+            plab_a2, plab_b2 = plab2[:usub], plab2[usub:]
+            loss_mask = torch.empty(lsub, *volume_batch.shape[2:], dtype=torch.int64, device=volume_batch.device)
+            ops.box_mask(loss_mask, self.box)
+            # ---- BCP mixing (:335-338): net_input_mix = cat(net_input_l, net_input_unl)
+            net_input_mix = torch.empty((lsub + usub,) + tuple(volume_batch.shape[1:]), dtype=torch.float32, device=volume_batch.device)
+            ops.box_mix(img_b, uimg_b, net_input_mix[:lsub], self.box)       # img_b*mask + uimg_b*(1-mask)
+            ops.box_mix(uimg_a, img_a, net_input_mix[lsub:], self.box)       # uimg_a*mask + img_a*(1-mask)
+
+        # ---- pass B + the four mix_loss terms (:339-351)
+        out_mix1, out_mix2 = model(net_input_mix, drop_masks=inject.get("drop_B"))
+        d1, d2 = torch.empty_like(out_mix1), torch.empty_like(out_mix2)
+        terms = (  # (logits, dlogits, img_l, patch_l, unlab)
+            (out_mix1[lsub:], d1[lsub:], plab_a2, lab_a, True),      # mix_loss1: out_unl1
+            (out_mix2[lsub:], d2[lsub:], plab_a1, lab_a, True),      # mix_loss2: out_unl2
+            (out_mix1[:lsub], d1[:lsub], lab_b, plab_b2, False),     # mix_loss3: out_l1
+            (out_mix2[:lsub], d2[:lsub], lab_b, plab_b1, False),     # mix_loss4: out_l2
+        )
+        losses = []
+        for lg, dl, img_l, patch_l, unlab in terms:
+            iw, pw = (0.5, 1.0) if unlab else (1.0, 0.5)            # l_weight=1.0, u_weight=0.5 (:198-203)
+            loss3, acc = ops.mix_loss_fwd(lg, img_l, patch_l, loss_mask, iw, pw)
+            ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, iw, pw, acc, dl)
+            losses.append(loss3)
+        torch.autograd.backward([out_mix1, out_mix2], [d1, d2])
+        if self.grad_sync is not None:
+            self.grad_sync.bucket_ready(0)
+
+        # ---- spatial adversarial perturbation (:368-375)
+        if a["adv_noise"]:
+            diff_mask = ops.diff_mask(pseudo_outputs1, pseudo_outputs2, knowledge, 4, a["topk1"])
+            vat_loss = self.adv_loss(model, volume_batch, outputs_soft1, outputs_soft2, diff_mask, a["adv_losstype"],
+                                     weight_dev=self.cw_dev, inject=inject)
+        else:
+            vat_loss = torch.zeros(1, dtype=torch.float32, device=volume_batch.device)
+        if self.grad_sync is not None:
+            self.grad_sync.bucket_ready(1)
+            self.grad_sync.wait()
+
+        # ---- optimizer.step() (:381-383)
+        if self.grad_sync is not None:
+            self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad_sync.second_bucket())
+        else:
+            self.opt.step()
+        return {"mix_losses": losses, "vat_loss": vat_loss}
+
+    def step(self, volume_batch, label_batch, box_yx=None, inject=None):
+        self._hw = tuple(volume_batch.shape[-2:])
+        self.prepare(box_yx)
+        out = self.device_step(volume_batch, label_batch, inject)
+        self.finish()
+        return out
+
+    # ------------------------------------------------------------------ HIP graph capture
+    def capture(self, volume_batch, label_batch, warmup=3):
+        """Capture device_step() into one HIP graph over static input buffers; afterwards call
+        replay(volume_batch, label_batch)."""
+        self._hw = tuple(volume_batch.shape[-2:])
+        self._static_v = volume_batch.clone()
+        self._static_l = label_batch.clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self.prepare()
+                self.device_step(self._static_v, self._static_l)
+                self.finish()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.model._rng.reset_counter()
+        g = torch.cuda.CUDAGraph()
+        self.prepare()
+        with torch.cuda.graph(g):
+            self.model._rng.seed_dev.add_(1)
+            self._static_out = self.device_step(self._static_v, self._static_l)
+        self.finish()
+        self._graph = g
+        return g
+
+    def replay(self, volume_batch, label_batch, box_yx=None):
+        self._static_v.copy_(volume_batch, non_blocking=True)
+        self._static_l.copy_(label_batch, non_blocking=True)
+        self.prepare(box_yx)
+        self._graph.replay()
+        self.finish()
+        return self._static_out

@@ -301,7 +301,8 @@ int chap_diff_mask(const chap_diffmask_params* p, void* stream);
 /* Fused SGD(momentum, weight decay) over a flat fp32 parameter buffer (train_ours_2D.py:278,383):
  * g = grad*grad_scale + wd*p; m = mu*m + g; p -= lr*m; optionally grad = 0.
  * lr is read from device memory so a captured graph can be replayed with a new value. */
-typedef struct { float* param; float* grad; float* mom; const float* lr; float momentum, weight_decay, grad_scale; int64_t n; int32_t zero_grad; } chap_sgd_params;
+typedef struct { float* param; float* grad; float* grad2 /* optional second bucket, summed */; float* mom; const float* lr;
+                 float momentum, weight_decay, grad_scale; int64_t n; int32_t zero_grad; } chap_sgd_params;
 int chap_sgd_step(const chap_sgd_params* p, void* stream);
 
 const char* chap_last_error(void);

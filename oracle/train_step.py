@@ -153,3 +153,96 @@ def sgd_step(params, grads, moms, lr, momentum=0.9, weight_decay=1e-4):
             gg = g + weight_decay * p
             m.mul_(momentum).add_(gg)
             p.sub_(lr * m)
+
+
+# --------------------------------------------------------------------------- the whole iteration
+ORACLE_ARGS = dict(base_lr=0.01, labeled_bs=12, max_iterations=30000, num_classes=4, consistency=1.0,
+                   consistency_rampup=50.0, noise_mag=10.0, epi=6.0, topk1=0.1, adv_noise=True, vat_iters=1,
+                   vat_sign=False, nms=1, momentum=0.9, weight_decay=1e-4)
+
+
+def iteration(sd, moms, volume_batch, label_batch, box_yx, iter_num, lr, args=None, inject=None, net=None):
+    """One iteration of train() (train_ours_2D.py:301-389) on CPU with the functional oracle nets.
+
+    sd: state dict whose float parameters require grad (updated in place); moms: name -> momentum
+    buffer; inject: {'drop_A','drop_B','drop_V0'..,'drop_VF': site->keep mask dicts, 'd0': VAT noise}.
+    Returns dict(losses=[4 x (loss_image, loss_patch, total)], vat_loss, bcp_loss, loss)."""
+    from . import nets
+    a = dict(ORACLE_ARGS)
+    a.update(args or {})
+    inject = inject or {}
+    net = net or nets.dual_decoder_2d
+    nc, lbs = a["num_classes"], a["labeled_bs"]
+    B = volume_batch.shape[0]
+    lsub, usub = lbs // 2, (B - lbs) // 2
+    img_a, img_b = volume_batch[:lsub], volume_batch[lsub:lbs]
+    uimg_a, uimg_b = volume_batch[lbs:lbs + usub], volume_batch[lbs + usub:]
+    lab_a, lab_b = label_batch[:lsub], label_batch[lsub:lbs]
+    uimg_ab = volume_batch[lbs:]
+    H, W = volume_batch.shape[-2:]
+    with torch.no_grad():
+        pre1, pre2 = net(sd, uimg_ab, train=True, drop=inject.get("drop_A"))
+        soft1, soft2, arg1, arg2, know = pseudo_block(pre1, pre2)
+        plab1 = largest_cc(arg1, nc) if a["nms"] else arg1
+        plab2 = largest_cc(arg2, nc) if a["nms"] else arg2
+        img_mask, loss_mask = box_masks(lsub, H, W, box_yx[0], box_yx[1])
+        net_input_unl = uimg_a * img_mask + img_a * (1 - img_mask)
+        net_input_l = img_b * img_mask + uimg_b * (1 - img_mask)
+        net_input_mix = torch.cat((net_input_l, net_input_unl))
+    out1, out2 = net(sd, net_input_mix, train=True, drop=inject.get("drop_B"))
+    out_l1, out_unl1 = out1[:lsub], out1[lsub:]
+    out_l2, out_unl2 = out2[:lsub], out2[lsub:]
+    m1 = mix_loss(out_unl1, plab2[:usub], lab_a, loss_mask, u_weight=0.5, unlab=True)
+    m2 = mix_loss(out_unl2, plab1[:usub], lab_a, loss_mask, u_weight=0.5, unlab=True)
+    m3 = mix_loss(out_l1, lab_b, plab2[usub:], loss_mask, u_weight=0.5)
+    m4 = mix_loss(out_l2, lab_b, plab1[usub:], loss_mask, u_weight=0.5)
+    bcp_loss = m1[2] + m2[2] + m3[2] + m4[2]
+    cw = consistency_weight(iter_num, a["consistency"], a["consistency_rampup"])
+    if a["adv_noise"]:
+        diff = create_mask_v1(arg1, arg2, know, 4, a["topk1"]).unsqueeze(1)
+        calls = {"k": 0}
+
+        def model_fn(xx):
+            k = calls["k"]
+            calls["k"] += 1
+            key = "drop_V%d" % k if k < a["vat_iters"] else "drop_VF"
+            return net(sd, xx, train=True, drop=inject.get(key), update_stats=False)
+
+        d0 = inject["d0"] if inject.get("d0") is not None else torch.rand(uimg_ab.shape) - 0.5
+        vat_loss, _ = vat2d(model_fn, uimg_ab, soft1, soft2, diff, d0, a["noise_mag"], a["epi"], a["vat_iters"], a["vat_sign"])
+    else:
+        vat_loss = torch.zeros(())
+    loss = bcp_loss + cw * vat_loss
+    names = [k for k, v in sd.items() if v.is_floating_point() and v.requires_grad]
+    grads = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
+    grads = [g if g is not None else torch.zeros_like(sd[k]) for g, k in zip(grads, names)]
+    sgd_step([sd[k] for k in names], grads, [moms[k] for k in names], lr, a["momentum"], a["weight_decay"])
+    return dict(losses=[m1, m2, m3, m4], vat_loss=vat_loss.detach(), bcp_loss=bcp_loss.detach(), loss=loss.detach(),
+                grads=dict(zip(names, grads)))
+
+
+def synthetic_batch(seed, n_lab, n_unlab, h, w, n_classes=4):
+    """Fixed-seed synthetic slices: sum of anisotropic Gaussian blobs + noise,
+    min-max normalised to [0,1]; labels = nested thresholds of the dominant blob (one region per class)."""
+    g = torch.Generator().manual_seed(seed)
+    n = n_lab + n_unlab
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    imgs = torch.zeros(n, 1, h, w)
+    labs = torch.zeros(n, h, w, dtype=torch.int64)
+    for i in range(n):
+        cy, cx = (0.3 + 0.4 * torch.rand(2, generator=g)) * torch.tensor([h, w])
+        sy, sx = (0.12 + 0.1 * torch.rand(2, generator=g)) * torch.tensor([h, w])
+        main = torch.exp(-(((yy - cy) / sy) ** 2 + ((xx - cx) / sx) ** 2))
+        img = main.clone()
+        for _ in range(int(torch.randint(2, 5, (1,), generator=g))):
+            by, bx = torch.rand(2, generator=g) * torch.tensor([h, w])
+            bs = (0.05 + 0.1 * torch.rand(1, generator=g)) * h
+            img += 0.5 * torch.rand(1, generator=g) * torch.exp(-(((yy - by) / bs) ** 2 + ((xx - bx) / bs) ** 2))
+        img += 0.05 * torch.randn(h, w, generator=g)
+        img = (img - img.min()) / (img.max() - img.min() + 1e-8)
+        imgs[i, 0] = img
+        lab = torch.zeros(h, w, dtype=torch.int64)
+        for c in range(1, n_classes):
+            lab[main > (0.25 + 0.5 * c / n_classes)] = c
+        labs[i] = lab
+    return imgs, labs

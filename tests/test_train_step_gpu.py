@@ -1,0 +1,83 @@
+"""One full CHAP iteration (pass A, BCP mix, four mix_loss terms, VAT power iteration + final pass,
+SGD) on the GPU in fp32 mode against the CPU oracle with identical injected randomness."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from chap_amd.networks import DualDecoder
+from chap_amd.train import ChapStep
+from oracle import init as oinit
+from oracle import train_step as ots
+
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def cl_masks(masks):
+    return {k: v.permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(DEV) for k, v in masks.items()}
+
+
+def test_iteration_matches_oracle():
+    B, lbs, H, W = 8, 4, 64, 64
+    U = B - lbs
+    args = dict(labeled_bs=lbs, batch_size=B, vat_iters=1)
+    state = oinit.dual_decoder_2d_state(301)
+    vol, lab = ots.synthetic_batch(1337, lbs, U, H, W)
+    inj_cpu = {"drop_A": oinit.drop_masks_2d(1, U, H, W), "drop_B": oinit.drop_masks_2d(2, lbs // 2 + U // 2, H, W),
+               "drop_V0": oinit.drop_masks_2d(3, U, H, W), "drop_VF": oinit.drop_masks_2d(4, U, H, W),
+               "d0": torch.rand(U, 1, H, W, generator=torch.Generator().manual_seed(5)) - 0.5}
+    box = (7, 11)
+    # ---- oracle
+    sd = {k: v.clone() for k, v in state.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    moms = {k: torch.zeros_like(v) for k, v in sd.items() if v.requires_grad}
+    ref = ots.iteration(sd, moms, vol, lab, box, iter_num=0, lr=0.01, args=args, inject=inj_cpu)
+    # ---- HIP path
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train()
+    m.load_state_dict(state, strict=True)
+    step = ChapStep(m, args)
+    inj = {k: (cl_masks(v) if k.startswith("drop") else v.to(DEV)) for k, v in inj_cpu.items()}
+    out = step.step(vol.to(DEV), lab.to(DEV), box_yx=box, inject=inj)
+    torch.cuda.synchronize()
+    for got, want in zip(out["mix_losses"], ref["losses"]):
+        assert relerr(got.cpu(), torch.stack([w.detach() for w in want])) < 2e-4
+    assert relerr(out["vat_loss"].cpu(), ref["vat_loss"].reshape(1)) < 5e-3
+    # parameters after the SGD step and BN running statistics (updated by passes A and B only)
+    after = m.state_dict()
+    worst = 0.0
+    for k, v in sd.items():
+        if not v.is_floating_point():
+            assert int(after[k]) == int(v), k
+            continue
+        d = (after[k].cpu().double() - v.detach().double()).abs().max().item()
+        upd = (v.detach().double() - state[k].double()).abs().max().item()
+        # compare the UPDATE (what the step changed) -- tolerance relative to the size of the update
+        if upd > 0:
+            worst = max(worst, d / upd)
+    assert worst < 0.1, worst
+    assert step.iter_num == 1 and abs(step.opt.param_groups[0]["lr"] - 0.01 * (1 - 1 / 30000) ** 0.9) < 1e-12
+
+
+def test_graph_capture_replay_runs():
+    torch.manual_seed(0)
+    B, lbs, H, W = 8, 4, 64, 64
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train().set_compute_dtype(torch.bfloat16)
+    step = ChapStep(m, dict(labeled_bs=lbs, batch_size=B))
+    vol, lab = ots.synthetic_batch(7, lbs, B - lbs, H, W)
+    vol, lab = vol.to(DEV), lab.to(DEV)
+    step.capture(vol, lab)
+    before = m.flat_buffers()[0].clone()
+    for _ in range(3):
+        out = step.replay(vol, lab)
+    torch.cuda.synchronize()
+    after = m.flat_buffers()[0]
+    assert torch.isfinite(after).all() and (after - before).abs().max() > 0
+    assert all(torch.isfinite(l).all() for l in out["mix_losses"]) and torch.isfinite(out["vat_loss"]).all()
