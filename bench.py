@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- CHAP training throughput on MI355X (BASELINE.json metric: training volumes/sec).
+
+    python bench.py --gpus N --steps K --warmup W [--config 2d|3d] [--dtype bf16|fp32]
+
+One "step" = one full iteration of train() (code/train_ours_2D.py:301-389): pass A on the unlabeled
+half, BCP mix, pass B fwd/bwd with the four mix_loss terms, VAT (K power iterations + final pass),
+SGD -- on a synthetic fixed-seed batch already resident in HBM.  N=1 workload = BASELINE config 1
+(ACDC 2D DualDecoder, bs=24 = 12 lab + 12 unlab, 256x256, 1 perturbation step, bf16).
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# ideal-fusion algorithmic bytes per training volume = (3.5 + K) * Bf
+BF_2D = {"bf16": 66.7e6, "fp32": 133.4e6}
+F_2D = 9.868e9                  # forward FLOPs per 256x256 slice
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="2d", choices=["2d"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=24)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--vat-iters", type=int, default=1)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, B, H):
+    """The oracle (CPU restatement, 'port') timed on this box's host cores on the same workload."""
+    from oracle import init as oinit
+    from oracle import train_step as ots
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    state = oinit.dual_decoder_2d_state(1337)
+    sd = {k: v.clone() for k, v in state.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    moms = {k: torch.zeros_like(v) for k, v in sd.items() if v.requires_grad}
+    vol, lab = ots.synthetic_batch(1337, B // 2, B - B // 2, H, H)
+    a = dict(labeled_bs=B // 2, vat_iters=args.vat_iters)
+    ots.iteration(sd, moms, vol, lab, (10, 20), 0, 0.01, args=a)          # warm-up
+    t0 = time.perf_counter()
+    for i in range(args.cpu_iters):
+        ots.iteration(sd, moms, vol, lab, (10 + i, 20), i + 1, 0.01, args=a)
+    dt = time.perf_counter() - t0
+    return {"value": B * args.cpu_iters / dt, "unit": "volumes/s", "cores": ncores, "kind": "port",
+            "sample": "%d iterations of the same bs=%d %dx%d iteration (oracle/train_step.py, fp32, torch CPU)" % (args.cpu_iters, B, H, H)}
+
+
+def dominant_kernel_roofline(model, dtype, N, H):
+    """HIP-event timing of the dominant kernel (the 16->16 3x3 implicit-GEMM conv at full resolution,
+    `conv_fwd_kernel<.., KC=16, NT=1>`) on the stream it is launched on, on the real layer shape."""
+    from chap_amd import _lib as L
+    from chap_amd import ops
+    dev = torch.device("cuda")
+    x = torch.randn(N, 1, H, H, 16, device=dev).to(dtype)
+    out = torch.empty_like(x)
+    w = torch.randn(16, 16, 3, 3, device=dev) / 12
+    scale, shift = torch.rand(16, device=dev) + 0.5, torch.randn(16, device=dev) * 0.1
+    stats = torch.zeros(8, 2, 16, device=dev)
+    wp = ops.pack_weights(w, L.PACK_CONV_FWD, dtype, 16, 16, 9)
+    src = ops.Lazy(x, scale, shift, True, 0.01)
+
+    def launch():
+        ops.conv_fwd([src], wp, None, 16, out, grid=(N, 1, H, H), in_dims=(1, H, H), ksize=3, stride=1, dims=2, stats=stats, stats_reps=8)
+
+    for _ in range(5):
+        launch()
+    reps = 50
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    esz = 2 if dtype == torch.bfloat16 else 4
+    alg_bytes = 2.0 * N * H * H * 16 * esz                      # read the input once + write the output once
+    ach = alg_bytes / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": None, "kernel": "conv_fwd_kernel<%s,3,1,2D,KC16,NT1> 16->16 @%dx%d N=%d" % ("bf16" if esz == 2 else "f32", H, H, N),
+            "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": alg_bytes}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in chap_amd)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from chap_amd.networks import DualDecoder
+    from chap_amd.train import ChapStep
+    from oracle import train_step as ots   # synthetic data generator only (data, not the checker)
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    B, H = args.batch, args.size
+    torch.manual_seed(1337)
+    model = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(dev).train().set_compute_dtype(dtype)
+    step = ChapStep(model, dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters), world_size=world)
+    if world > 1:
+        from chap_amd.parallel import DataParallelSync
+        step.grad_sync = DataParallelSync(model, dist)
+    vol, lab = ots.synthetic_batch(1337 + rank, B // 2, B - B // 2, H, H)    # each rank: its own shard (weak scaling)
+    vol, lab = vol.to(dev), lab.to(dev)
+    use_graph = (not args.no_graph) and world == 1
+    if use_graph:
+        step.capture(vol, lab, warmup=2)
+        run = lambda: step.replay(vol, lab)                                    # noqa: E731
+    else:
+        run = lambda: step.step(vol, lab)                                      # noqa: E731
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    finite = bool(torch.isfinite(out["vat_loss"]).all()) and all(bool(torch.isfinite(l).all()) for l in out["mix_losses"])
+    vps = B * world * args.steps / dt
+    if rank == 0:
+        K = args.vat_iters
+        bytes_per_vol = (3.5 + K) * BF_2D[args.dtype] * (H * H) / (256 * 256)
+        flops_per_vol = (3.5 + K) * F_2D * (H * H) / (256 * 256)
+        roof = dominant_kernel_roofline(model, dtype, B // 2, H)
+        roof["iteration_hbm_frac_vs_ideal_fusion"] = round(vps / world * bytes_per_vol / 1e9 / HBM_PEAK_GBS, 4)
+        roof["iteration_tflops"] = round(vps / world * flops_per_vol / 1e12, 2)
+        line = {"metric": "training volumes/sec (2D 256^2 bs24)", "value": round(vps, 2), "unit": "volumes/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "config": {"workload": "ACDC 2D DualDecoder bs=%d (%d lab + %d unlab) %dx%d, %d perturb step(s), N_v=U" % (B, B // 2, B - B // 2, H, H, K),
+                           "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": use_graph, "losses_finite": finite},
+                "roofline": roof}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args, B, H)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

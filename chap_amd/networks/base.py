@@ -135,6 +135,14 @@ class ChapNet(nn.Module):
         self._grad_views()
         return self._flat, self._flat_grad
 
+    def swap_grad_buffer(self, new_flat_grad):
+        """Point p.grad at another flat buffer of the same layout (DP bucket schedule); contents are
+        left untouched."""
+        assert new_flat_grad.shape == self._flat_grad.shape
+        self._flat_grad = new_flat_grad
+        for (name, p), o in zip(self._param_list(), self._offsets):
+            p.grad = new_flat_grad[o:o + p.numel()].view(p.shape)
+
     def _eval_invstd(self, bn, rv):
         return (rv + 1e-5).rsqrt()
 

@@ -52,7 +52,7 @@ def test_iteration_matches_oracle():
     assert relerr(out["vat_loss"].cpu(), ref["vat_loss"].reshape(1)) < 5e-3
     # parameters after the SGD step and BN running statistics (updated by passes A and B only)
     after = m.state_dict()
-    worst = 0.0
+    worst, worst_key = 0.0, None
     for k, v in sd.items():
         if not v.is_floating_point():
             assert int(after[k]) == int(v), k
@@ -60,9 +60,10 @@ def test_iteration_matches_oracle():
         d = (after[k].cpu().double() - v.detach().double()).abs().max().item()
         upd = (v.detach().double() - state[k].double()).abs().max().item()
         # compare the UPDATE (what the step changed) -- tolerance relative to the size of the update
-        if upd > 0:
-            worst = max(worst, d / upd)
-    assert worst < 0.1, worst
+        floor = 3e-7 * v.detach().abs().max().item()       # a few fp32 ulps (weight-decay-only updates)
+        if upd > 0 and max(d - floor, 0.0) / upd > worst:
+            worst, worst_key = max(d - floor, 0.0) / upd, k
+    assert worst < 0.05, (worst, worst_key)
     assert step.iter_num == 1 and abs(step.opt.param_groups[0]["lr"] - 0.01 * (1 - 1 / 30000) ** 0.9) < 1e-12
 
 
