@@ -20,6 +20,8 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+T_START = time.perf_counter()
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 # ideal-fusion algorithmic bytes per training volume = (3.5 + K) * Bf
 BF_2D = {"bf16": 66.7e6, "fp32": 133.4e6}
@@ -42,12 +44,29 @@ def parse():
     return ap.parse_args()
 
 
+def log(msg):
+    print("[bench %6.1fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(args, B, H):
     """The oracle (CPU restatement, 'port') timed on this box's host cores on the same workload."""
     from oracle import init as oinit
     from oracle import train_step as ots
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     torch.set_num_threads(ncores)
+    log("cpu_baseline: %d threads" % ncores)
     state = oinit.dual_decoder_2d_state(1337)
     sd = {k: v.clone() for k, v in state.items()}
     for k, v in sd.items():
@@ -57,6 +76,7 @@ def cpu_baseline(args, B, H):
     vol, lab = ots.synthetic_batch(1337, B // 2, B - B // 2, H, H)
     a = dict(labeled_bs=B // 2, vat_iters=args.vat_iters)
     ots.iteration(sd, moms, vol, lab, (10, 20), 0, 0.01, args=a)          # warm-up
+    log("cpu_baseline: warm-up iteration done")
     t0 = time.perf_counter()
     for i in range(args.cpu_iters):
         ots.iteration(sd, moms, vol, lab, (10 + i, 20), i + 1, 0.01, args=a)
@@ -130,14 +150,17 @@ def main():
     vol, lab = ots.synthetic_batch(1337 + rank, B // 2, B - B // 2, H, H)    # each rank: its own shard (weak scaling)
     vol, lab = vol.to(dev), lab.to(dev)
     use_graph = (not args.no_graph) and world == 1
+    log("model + data ready (B=%d, %dx%d, %s)" % (B, H, H, args.dtype))
     if use_graph:
         step.capture(vol, lab, warmup=2)
+        log("graph captured")
         run = lambda: step.replay(vol, lab)                                    # noqa: E731
     else:
         run = lambda: step.step(vol, lab)                                      # noqa: E731
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
+    log("warm-up done")
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
@@ -151,6 +174,7 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    log("timed region done: %.1f ms/step" % (dt / args.steps * 1e3))
     finite = bool(torch.isfinite(out["vat_loss"]).all()) and all(bool(torch.isfinite(l).all()) for l in out["mix_losses"])
     vps = B * world * args.steps / dt
     if rank == 0:

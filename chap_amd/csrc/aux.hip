@@ -216,3 +216,13 @@ extern "C" int chap_sgd_step(const chap_sgd_params* p, void* stream) {
     CHAP_LAUNCH_CHECK("chap_sgd_step");
     return CHAP_OK;
 }
+
+// ---- bandwidth calibration (tools/membw.py): float4 copy ------------------------------------------
+__global__ void copy_kernel(const float4* __restrict__ a, float4* __restrict__ b, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) b[i] = a[i];
+}
+extern "C" int chap_debug_copy(const void* src, void* dst, int64_t bytes, int32_t blocks, void* stream) {
+    hipLaunchKernelGGL(copy_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, (long)(bytes / 16));
+    CHAP_LAUNCH_CHECK("chap_debug_copy");
+    return CHAP_OK;
+}

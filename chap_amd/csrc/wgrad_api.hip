@@ -35,23 +35,34 @@ extern "C" size_t chap_wgrad_ws(const chap_wgrad_params* p) {
     return q.bytes;
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_db, int nsplit, int taps, int Ca, int Cb,
-                                    float* dw, long s_tap, long s_kc, long s_kn, int kc_valid, int kn_valid, float* db) {
+// Deterministic slab reduction: a block owns 16 consecutive dW elements and splits the slabs over
+// 16 thread groups (fixed order inside a group, fixed tree across groups), so the result does not
+// depend on scheduling.  Loads are 64-byte segments of each slab; 16*ceil(total/16) threads.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_db, int nsplit, int taps, int Ca, int Cb,
+                                                           float* dw, long s_tap, long s_kc, long s_kn, int kc_valid, int kn_valid, float* db) {
+    __shared__ float red[16][17];
     const long total = (long)taps * Ca * Cb;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) {
-        const int kn = (int)(i % Cb); long r = i / Cb;
+    const int e = threadIdx.x & 15, sg = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + e;
+    float s = 0.f;
+    if (i < total)
+        for (int k = sg; k < nsplit; k += 16) s += ws[(long)k * total + i];
+    red[sg][e] = s;
+    __syncthreads();
+    if (sg == 0 && i < total) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][e];
+        const int kn = (int)(i % Cb); const long r = i / Cb;
         const int kc = (int)(r % Ca); const int tap = (int)(r / Ca);
-        if (kc < kc_valid && kn < kn_valid) {
-            float s = 0.f;
-            for (int k = 0; k < nsplit; ++k) s += ws[(long)k * total + i];
-            dw[tap * s_tap + kc * s_kc + kn * s_kn] += s;
-        }
+        if (kc < kc_valid && kn < kn_valid) dw[tap * s_tap + kc * s_kc + kn * s_kn] += t;
     }
-    if (db != nullptr && i < Cb && i < kn_valid) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += ws_db[(long)k * Cb + i];
-        db[i] += s;
+    if (db != nullptr && blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < Cb && c < kn_valid; c += 256) {
+            float t = 0.f;
+            for (int k = 0; k < nsplit; ++k) t += ws_db[(long)k * Cb + c];
+            db[c] += t;
+        }
     }
 }
 
@@ -73,7 +84,7 @@ extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     if (r) return r;
     const long total = (long)q.taps * q.Ca * q.Cb;
     const int kcv = p->kc_valid > 0 ? p->kc_valid : q.Ca, knv = p->kn_valid > 0 ? p->kn_valid : q.Cb;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)ws, (const float*)ws_db, q.nsplit, q.taps, q.Ca, q.Cb,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 16)), dim3(256), 0, s, (const float*)ws, (const float*)ws_db, q.nsplit, q.taps, q.Ca, q.Cb,
                        p->dw, (long)p->s_tap, (long)p->s_kc, (long)p->s_kn, kcv, knv, p->db);
     CHAP_LAUNCH_CHECK("chap_wgrad(reduce)");
     return CHAP_OK;

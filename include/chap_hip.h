@@ -305,6 +305,9 @@ typedef struct { float* param; float* grad; float* grad2 /* optional second buck
                  float momentum, weight_decay, grad_scale; int64_t n; int32_t zero_grad; } chap_sgd_params;
 int chap_sgd_step(const chap_sgd_params* p, void* stream);
 
+/* Bandwidth calibration helper (tools/membw.py): grid-stride float4 copy with `blocks` blocks of 256. */
+int chap_debug_copy(const void* src, void* dst, int64_t bytes, int32_t blocks, void* stream);
+
 const char* chap_last_error(void);
 int chap_abi_version(void);
 

@@ -1,0 +1,43 @@
+"""Time single kernels on real layer shapes (HIP events on the launch stream)."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from chap_amd import _lib as L, ops
+
+dev = "cuda"
+
+def timeit(fn, reps=30):
+    for _ in range(5): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+def conv_case(N, H, cin, cout, dtype, stats, prologue, ks=3):
+    x = torch.randn(N, 1, H, H, cin, device=dev).to(dtype)
+    out = torch.empty(N, 1, H, H, cout, device=dev, dtype=dtype)
+    w = torch.randn(cout, cin, ks, ks, device=dev) / 12
+    wp = ops.pack_weights(w, L.PACK_CONV_FWD, dtype, cin, cout, ks * ks)
+    sc, sh = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1
+    st = torch.zeros(8, 2, cout, device=dev) if stats else None
+    src = ops.Lazy(x, sc, sh, True, 0.01) if prologue else ops.Lazy(x)
+    us = timeit(lambda: ops.conv_fwd([src], wp, None, cout, out, grid=(N, 1, H, H), in_dims=(1, H, H), ksize=ks, stride=1, dims=2, stats=st, stats_reps=8))
+    esz = 2 if dtype == torch.bfloat16 else 4
+    by = N * H * H * (cin + cout) * esz
+    fl = 2.0 * N * H * H * cin * cout * ks * ks
+    print("conv%dx%d %3d->%3d @%3d N=%d %s stats=%d prologue=%d: %8.1f us  %7.1f GB/s  %6.1f TFLOP/s" % (ks, ks, cin, cout, H, N, "bf16" if esz == 2 else "f32", stats, prologue, us, by / us / 1e3, fl / us / 1e6))
+
+if __name__ == "__main__":
+    bf = torch.bfloat16
+    for stats in (0, 1):
+        for pro in (0, 1):
+            conv_case(12, 256, 16, 16, bf, stats, pro)
+    conv_case(12, 128, 32, 32, bf, 1, 1)
+    conv_case(12, 64, 64, 64, bf, 1, 1)
+    conv_case(12, 32, 128, 128, bf, 1, 1)
+    conv_case(12, 16, 256, 256, bf, 1, 1)
+    conv_case(12, 256, 32, 16, bf, 1, 1)
+    conv_case(12, 128, 64, 32, bf, 1, 1)
+    conv_case(12, 16, 256, 128, bf, 0, 1, ks=1)
+    conv_case(12, 256, 16, 16, torch.float32, 1, 1)
