@@ -400,8 +400,11 @@ extern "C" int chap_upsample2x_bwd(const chap_upsample_bwd_params* p, void* stre
 // Backward through the lazy activation (+ pooled consumer) and training-mode BatchNorm.
 // Thread = (pixel, 8 channels); a block covers 256/C8 pixels per step, grid-stride; per-channel
 // partial sums are reduced over the block in LDS and flushed with one atomic per channel.
+struct act_consts { float a[8], b[8], cm_dummy; };
+
 template <typename T>
-__device__ __forceinline__ void act_bwd_dz(const chap_act_bwd_params& P, int n, long pix, int y, int x, int c8, float raw[8], float dz[8]) {
+__device__ __forceinline__ void act_bwd_dz(const chap_act_bwd_params& P, const float sa[8], const float sb[8], int n, long pix, int y, int x, int c8,
+                                           float raw[8], float dz[8]) {
     const chap_src_t& s = P.r;
     const int C = s.C;
     ld8((const T*)s.ptr + pix * s.ld + s.coff + c8, raw);
@@ -428,11 +431,9 @@ __device__ __forceinline__ void act_bwd_dz(const chap_act_bwd_params& P, int n, 
         }
     }
     // a = keep*ks*cm*leaky(z), z = scale*raw+shift  ->  da/dz = keep*ks*cm*(z>0 ? 1 : slope)
-    float a[8], b[8];
-    if (s.scale) { ld8(s.scale + c8, a); ld8(s.shift + c8, b); }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float z = s.scale ? fmaf(raw[j], a[j], b[j]) : raw[j];
+        const float z = fmaf(raw[j], sa[j], sb[j]);
         float d = gsum[j];
         if (s.act) d *= (z > 0.f ? 1.f : s.slope);
         dz[j] = d;
@@ -460,9 +461,10 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
     const long npix = (long)P.N * P.D * P.H * P.W;
     const int c8 = (threadIdx.x % C8) * 8;
     const int prow = threadIdx.x / C8, PPB = 256 / C8;      // C8 in {2,4,8,...,32} divides 256
-    float s0[8], s1[8], mean[8], istd[8], k0[8], k1[8], k2[8];
+    float s0[8], s1[8], mean[8], istd[8], k0[8], k1[8], k2[8], sa[8], sb[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; }
+    for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; sa[j] = 1.f; sb[j] = 0.f; }
+    if (P.r.scale) { ld8(P.r.scale + c8, sa); ld8(P.r.shift + c8, sb); }      // per-channel constants: loaded once
 #pragma unroll
     for (int j = 0; j < 8; ++j) { k0[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; mean[j] = 0.f; istd[j] = 1.f; }
     if (P.bn) { ld8(P.mean + c8, mean); ld8(P.invstd + c8, istd); }
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
             const int y = (int)(r % P.H); r /= P.H;
             const int n = (int)(r / P.D);
             float raw[8], dz[8];
-            act_bwd_dz<T>(P, n, pix, y, x, c8, raw, dz);
+            act_bwd_dz<T>(P, sa, sb, n, pix, y, x, c8, raw, dz);
             if (!APPLY) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { s0[j] += dz[j]; s1[j] += dz[j] * (raw[j] - mean[j]) * istd[j]; }

@@ -1,0 +1,60 @@
+// Stand-alone ablation harness for conv_fwd_kernel (build with -DCHAP_ABLATE=<bits>):
+//   1 skip MFMA (LDS fragment reads kept alive)   2 skip the whole tap loop
+//   4 force the plain (no transform) commit path  8 skip global stores   16 skip halo global loads
+#include "conv_kernel.h"
+#include <vector>
+#include <cstdio>
+#include <cstdlib>
+void chap_set_error(const char* fmt, ...) {}
+
+template <int KS, int KC, int NT, int MR, bool WLDS>
+static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool prologue, bool stats) {
+    typedef uint16_t T;
+    typedef conv_geom<KS, 1, false, MR> G;
+    constexpr int GPT = KC / 8, NP = G::NTAPS * GPT, STEPS = (NP + 3) / 4;
+    const int nchunks = Cin / KC, ntile16 = (Cout + 15) / 16;
+    size_t nin = (size_t)N * H * W * Cin, nout = (size_t)N * H * W * Cout;
+    T *x, *y, *wp; float *sc, *sh, *st;
+    hipMalloc(&x, nin * 2); hipMalloc(&y, nout * 2);
+    size_t wbytes_all = (size_t)nchunks * STEPS * ntile16 * 64 * 8 * 2;
+    hipMalloc(&wp, wbytes_all); hipMalloc(&sc, Cin * 4); hipMalloc(&sh, Cin * 4); hipMalloc(&st, 8 * 2 * Cout * 4);
+    std::vector<T> hx(nin); for (size_t i = 0; i < nin; ++i) hx[i] = 0x3c00 + (rand() & 0x3ff);
+    hipMemcpy(x, hx.data(), nin * 2, hipMemcpyHostToDevice);
+    std::vector<T> hw(wbytes_all / 2); for (auto& v : hw) v = 0x3800 + (rand() & 0xff);
+    hipMemcpy(wp, hw.data(), wbytes_all, hipMemcpyHostToDevice);
+    std::vector<float> hs(Cin, 1.01f); hipMemcpy(sc, hs.data(), Cin * 4, hipMemcpyHostToDevice); hipMemcpy(sh, hs.data(), Cin * 4, hipMemcpyHostToDevice);
+    hipMemset(st, 0, 8 * 2 * Cout * 4);
+    chap_conv_params P = {};
+    P.src[0].ptr = x; P.src[0].C = Cin; P.src[0].ld = Cin; P.src[0].slope = 0.01f; P.src[0].keep_scale = 1.f;
+    if (prologue) { P.src[0].scale = sc; P.src[0].shift = sh; P.src[0].act = 1; }
+    P.nsrc = 1; P.N = N; P.D = 1; P.H = H; P.W = W; P.ID = 1; P.IH = H; P.IW = W; P.ksize = KS; P.stride = 1; P.dims = 2;
+    P.wpacked = wp; P.out = y; P.Cout = Cout; P.out_ld = Cout; P.stats = stats ? st : nullptr; P.stats_reps = 8; P.dtype = CHAP_BF16;
+    auto kern = conv_fwd_kernel<T, KS, 1, false, KC, NT, MR, false, WLDS>;
+    size_t lds = conv_lds_fixed_bytes<T, KS, 1, false, KC, MR>(NT) + 2 * CONV_MAX_AFFINE_C * 4 + (WLDS ? (size_t)nchunks * STEPS * NT * 1024 : 0);
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, lds);
+    long ntiles = (long)N * ((H + G::TH - 1) / G::TH) * ((W + 15) / 16);
+    int gy = (ntile16 + NT - 1) / NT;
+    for (int bpc = 1; bpc <= 8; bpc *= 2) {
+        long gx = std::min<long>((ntiles + 7) / 8 * 8, (long)256 * bpc / gy / 8 * 8);
+        if (gx < 8) gx = 8;
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, 0, P);
+        hipEventRecord(e0);
+        for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, 0, P);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double us = ms * 1e3 / 20, gb = (double)(nin + nout) * 2 / us / 1e3;
+        printf("abl=%2d %-28s occ=%d grid=%5ldx%d lds=%6zu : %8.1f us %7.1f GB/s\n", CHAP_ABLATE, name, occ, gx, gy, lds, us, gb);
+    }
+    hipFree(x); hipFree(y); hipFree(wp); hipFree(sc); hipFree(sh); hipFree(st);
+}
+
+int main() {
+    run<3, 16, 1, 4, true>("16->16@256 MR4 pro+stats", 12, 256, 256, 16, 16, true, true);
+    run<3, 16, 1, 2, true>("16->16@256 MR2 pro+stats", 12, 256, 256, 16, 16, true, true);
+    run<3, 32, 2, 4, true>("32->32@128 MR4 pro+stats", 12, 128, 128, 32, 32, true, true);
+    run<3, 32, 4, 2, true>("64->64@64 MR2 pro+stats", 12, 64, 64, 64, 64, true, true);
+    run<3, 32, 4, 2, false>("128->128@32 MR2", 12, 32, 32, 128, 128, true, true);
+    return 0;
+}
