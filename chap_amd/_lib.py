@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libchap_hip.so")
 
 F32, BF16 = 0, 1
+ACT_BWD_REPS = 32          # CHAP_ACT_BWD_REPS
 PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_DECONV_FWD, PACK_DECONV_DGRAD, PACK_DOWN_DGRAD = range(5)
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t

@@ -17,12 +17,10 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const chap_conv_c1_par
     for (int i = threadIdx.x; i < 2 * CO; i += 256) bstat[i] = 0.f;
     __syncthreads();
     const long npix = (long)P.N * P.D * P.H * P.W;
-    const long pix = (long)blockIdx.x * 256 + threadIdx.x;
-    float acc[CO];
+    float ssum[CO], ssq[CO];
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-    const bool valid = pix < npix;
-    if (valid) {
+    for (int c = 0; c < CO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
+    for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
         const int x = (int)(pix % P.W); long r = pix / P.W;
         const int y = (int)(r % P.H); r /= P.H;
         const int z = (int)(r % P.D); const int n = (int)(r / P.D);
@@ -37,12 +35,13 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const chap_conv_c1_par
                     const bool ib = (unsigned)zz < (unsigned)P.D && (unsigned)yy < (unsigned)P.H && (unsigned)xx < (unsigned)P.W;
                     in[(dz * 3 + dy) * 3 + dx] = ib ? P.x[(((long)n * P.D + zz) * P.H + yy) * P.W + xx] : 0.f;
                 }
+        float acc[CO];
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
             float a = ws[CO * TAPS + c];
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) a = fmaf(in[t], ws[c * TAPS + t], a);
-            acc[c] = a;
+            acc[c] = a; ssum[c] += a; ssq[c] += a * a;
         }
         T* o = (T*)P.out + pix * CO;
 #pragma unroll
@@ -51,8 +50,7 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const chap_conv_c1_par
     if (P.stats) {
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
-            const float v = valid ? acc[c] : 0.f;
-            const float s = wave_sum(v), q = wave_sum(v * v);
+            const float s = wave_sum(ssum[c]), q = wave_sum(ssq[c]);
             if ((threadIdx.x & 63) == 0) { atomicAdd(&bstat[c], s); atomicAdd(&bstat[CO + c], q); }
         }
         __syncthreads();
@@ -66,7 +64,7 @@ extern "C" int chap_conv_c1_fwd(const chap_conv_c1_params* p, void* stream) {
     CHAP_CHECK_ARG(p->Cout == 16, "chap_conv_c1_fwd: Cout=%d (only 16 built)", p->Cout);
     CHAP_CHECK_ARG(p->dims == 2 || p->dims == 3, "chap_conv_c1_fwd: dims=%d", p->dims);
     const long npix = (long)p->N * p->D * p->H * p->W;
-    dim3 grid((unsigned)cdiv(npix, 256));
+    dim3 grid((unsigned)(cdiv(npix, 256) < 2048 ? cdiv(npix, 256) : 2048));
     hipStream_t s = (hipStream_t)stream;
     const bool d3 = p->dims == 3, bf = p->dtype == CHAP_BF16;
     if (bf && d3) hipLaunchKernelGGL((conv_c1_fwd_kernel<bf16_t, true, 16>), grid, dim3(256), 0, s, *p);
@@ -163,13 +161,19 @@ __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const chap_conv_c1_bwd
 }
 
 template <int CO>
-__global__ void conv_c1_reduce_kernel(const float* ws, int nblocks, int taps, float* dw, float* db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void conv_c1_reduce_kernel(const float* ws, int nblocks, int taps, float* dw, float* db) {
+    __shared__ float red[4];
+    const int i = blockIdx.x;                    // one block per output element, threads stride the block partials
     const int tot = CO * taps + CO;
-    if (i >= tot) return;
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += ws[(long)b * tot + i];
-    if (i < CO * taps) { if (dw) dw[i] += s; } else if (db) db[i - CO * taps] += s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += ws[(long)b * tot + i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (red[0] + red[1]) + (red[2] + red[3]);
+        if (i < CO * taps) { if (dw) dw[i] += s; } else if (db) db[i - CO * taps] += s;
+    }
 }
 
 static int c1_bwd_blocks(const chap_conv_c1_bwd_params* p) {
@@ -195,7 +199,7 @@ extern "C" int chap_conv_c1_bwd(const chap_conv_c1_bwd_params* p, void* stream) 
     CHAP_LAUNCH_CHECK("chap_conv_c1_bwd");
     if (p->dw || p->db) {
         const int taps = d3 ? 27 : 9, tot = 16 * taps + 16;
-        hipLaunchKernelGGL((conv_c1_reduce_kernel<16>), dim3(cdiv(tot, 256)), dim3(256), 0, s, (const float*)p->ws, nb, taps, p->dw, p->db);
+        hipLaunchKernelGGL((conv_c1_reduce_kernel<16>), dim3(tot), dim3(256), 0, s, (const float*)p->ws, nb, taps, p->dw, p->db);
         CHAP_LAUNCH_CHECK("chap_conv_c1_bwd(reduce)");
     }
     return CHAP_OK;
@@ -400,7 +404,7 @@ extern "C" int chap_upsample2x_bwd(const chap_upsample_bwd_params* p, void* stre
 // Backward through the lazy activation (+ pooled consumer) and training-mode BatchNorm.
 // Thread = (pixel, 8 channels); a block covers 256/C8 pixels per step, grid-stride; per-channel
 // partial sums are reduced over the block in LDS and flushed with one atomic per channel.
-struct act_consts { float a[8], b[8], cm_dummy; };
+constexpr int ACT_BWD_REPS = CHAP_ACT_BWD_REPS;   // sums layout: [REPS][2][C]
 
 template <typename T>
 __device__ __forceinline__ void act_bwd_dz(const chap_act_bwd_params& P, const float sa[8], const float sb[8], int n, long pix, int y, int x, int c8,
@@ -470,7 +474,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
     if (P.bn) { ld8(P.mean + c8, mean); ld8(P.invstd + c8, istd); }
     if (APPLY) {
         if (P.bn == 1) {                               // training-mode BatchNorm backward
-            float gm[8], a0[8], a1[8];
+            float gm[8], a0[8], a1[8];          // replica 0 holds the compacted totals (act_bwd_param_kernel)
             ld8(P.gamma + c8, gm); ld8(P.sums + c8, a0); ld8(P.sums + C + c8, a1);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { k0[j] = gm[j] * istd[j]; k1[j] = a0[j] / P.count; k2[j] = a1[j] / P.count; }
@@ -505,15 +509,21 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
             for (int j = 0; j < 8; ++j) { atomicAdd(&red[c8 + j], s0[j]); atomicAdd(&red[C + c8 + j], s1[j]); }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&P.sums[i], red[i]);
+        float* dst = P.sums + (long)(blockIdx.x % ACT_BWD_REPS) * 2 * C;
+        for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&dst[i], red[i]);
     }
 }
 
-__global__ void act_bwd_param_kernel(const float* sums, float* dgamma, float* dbeta, int C) {
+// Sums the replicas of the reduce phase into replica 0 (read by the apply phase) and accumulates the
+// BatchNorm parameter gradients.
+__global__ void act_bwd_param_kernel(float* sums, float* dgamma, float* dbeta, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    if (dbeta) dbeta[c] += sums[c];
-    if (dgamma) dgamma[c] += sums[C + c];
+    float a = 0.f, b = 0.f;
+    for (int r = 0; r < ACT_BWD_REPS; ++r) { a += sums[(long)r * 2 * C + c]; b += sums[(long)r * 2 * C + C + c]; }
+    sums[c] = a; sums[C + c] = b;
+    if (dbeta) dbeta[c] += a;
+    if (dgamma) dgamma[c] += b;
 }
 
 static int act_bwd_check(const chap_act_bwd_params* p) {
@@ -538,6 +548,8 @@ extern "C" int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream) {
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, false>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL((act_bwd_kernel<float, false>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_act_bwd_reduce");
+    hipLaunchKernelGGL(act_bwd_param_kernel, dim3(cdiv(p->r.C, 64)), dim3(64), 0, (hipStream_t)stream, p->sums, p->dgamma, p->dbeta, p->r.C);
+    CHAP_LAUNCH_CHECK("chap_act_bwd_reduce(params)");
     return CHAP_OK;
 }
 extern "C" int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream) {
@@ -546,10 +558,6 @@ extern "C" int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream) {
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, true>), dim3(act_bwd_blocks(p)), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL((act_bwd_kernel<float, true>), dim3(act_bwd_blocks(p)), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_act_bwd_apply");
-    if (p->bn && (p->dgamma || p->dbeta)) {
-        hipLaunchKernelGGL(act_bwd_param_kernel, dim3(cdiv(p->r.C, 64)), dim3(64), 0, (hipStream_t)stream, (const float*)p->sums, p->dgamma, p->dbeta, p->r.C);
-        CHAP_LAUNCH_CHECK("chap_act_bwd_apply(params)");
-    }
     return CHAP_OK;
 }
 

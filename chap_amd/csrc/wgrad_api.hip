@@ -35,33 +35,41 @@ extern "C" size_t chap_wgrad_ws(const chap_wgrad_params* p) {
     return q.bytes;
 }
 
-// Deterministic slab reduction: a block owns 16 consecutive dW elements and splits the slabs over
-// 16 thread groups (fixed order inside a group, fixed tree across groups), so the result does not
-// depend on scheduling.  Loads are 64-byte segments of each slab; 16*ceil(total/16) threads.
+// Deterministic slab reduction: a block owns 8 consecutive elements and splits the slabs over
+// 32 thread groups; each thread keeps 4 independent partial sums so that 4 loads are in flight
+// (the loop is latency-bound otherwise).  Fixed summation order -> bitwise reproducible.
+// Blocks [0, nb_dw) reduce dW, blocks [nb_dw, ...) reduce the bias-gradient partials the same way.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_db, int nsplit, int taps, int Ca, int Cb,
-                                                           float* dw, long s_tap, long s_kc, long s_kn, int kc_valid, int kn_valid, float* db) {
-    __shared__ float red[16][17];
-    const long total = (long)taps * Ca * Cb;
-    const int e = threadIdx.x & 15, sg = threadIdx.x >> 4;
-    const long i = (long)blockIdx.x * 16 + e;
-    float s = 0.f;
-    if (i < total)
-        for (int k = sg; k < nsplit; k += 16) s += ws[(long)k * total + i];
-    red[sg][e] = s;
+                                                           float* dw, long s_tap, long s_kc, long s_kn, int kc_valid, int kn_valid, float* db, int nb_dw) {
+    __shared__ float red[32][9];
+    const bool is_db = (int)blockIdx.x >= nb_dw;
+    const float* src = is_db ? ws_db : ws;
+    const long total = is_db ? (long)Cb : (long)taps * Ca * Cb;
+    const int e = threadIdx.x & 7, sg = threadIdx.x >> 3;
+    const long i = (long)(is_db ? blockIdx.x - nb_dw : blockIdx.x) * 8 + e;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < total) {
+        int k = sg;
+        for (; k + 96 < nsplit; k += 128) {
+            s0 += src[(long)k * total + i];
+            s1 += src[(long)(k + 32) * total + i];
+            s2 += src[(long)(k + 64) * total + i];
+            s3 += src[(long)(k + 96) * total + i];
+        }
+        for (; k < nsplit; k += 32) s0 += src[(long)k * total + i];
+    }
+    red[sg][e] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sg == 0 && i < total) {
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += red[k][e];
-        const int kn = (int)(i % Cb); const long r = i / Cb;
-        const int kc = (int)(r % Ca); const int tap = (int)(r / Ca);
-        if (kc < kc_valid && kn < kn_valid) dw[tap * s_tap + kc * s_kc + kn * s_kn] += t;
-    }
-    if (db != nullptr && blockIdx.x == 0) {
-        for (int c = threadIdx.x; c < Cb && c < kn_valid; c += 256) {
-            float t = 0.f;
-            for (int k = 0; k < nsplit; ++k) t += ws_db[(long)k * Cb + c];
-            db[c] += t;
+        for (int k = 0; k < 32; ++k) t += red[k][e];
+        if (is_db) {
+            if (i < kn_valid) db[i] += t;
+        } else {
+            const int kn = (int)(i % Cb); const long r = i / Cb;
+            const int kc = (int)(r % Ca); const int tap = (int)(r / Ca);
+            if (kc < kc_valid && kn < kn_valid) dw[tap * s_tap + kc * s_kc + kn * s_kn] += t;
         }
     }
 }
@@ -84,8 +92,9 @@ extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     if (r) return r;
     const long total = (long)q.taps * q.Ca * q.Cb;
     const int kcv = p->kc_valid > 0 ? p->kc_valid : q.Ca, knv = p->kn_valid > 0 ? p->kn_valid : q.Cb;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 16)), dim3(256), 0, s, (const float*)ws, (const float*)ws_db, q.nsplit, q.taps, q.Ca, q.Cb,
-                       p->dw, (long)p->s_tap, (long)p->s_kc, (long)p->s_kn, kcv, knv, p->db);
+    const int nb_dw = cdiv(total, 8), nb_db = p->db ? cdiv(q.Cb, 8) : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb_dw + nb_db), dim3(256), 0, s, (const float*)ws, (const float*)ws_db, q.nsplit, q.taps, q.Ca, q.Cb,
+                       p->dw, (long)p->s_tap, (long)p->s_kc, (long)p->s_kn, kcv, knv, p->db, nb_dw);
     CHAP_LAUNCH_CHECK("chap_wgrad(reduce)");
     return CHAP_OK;
 }

@@ -227,6 +227,16 @@ class Executor:
         head_g = dict(zip(prog.heads, dlogits))
         dx = None
         nsub = 2 ** dims
+        # one zeroed arena for the BN-backward partial sums of every layer (a single memset per pass)
+        nsum = sum(L.ACT_BWD_REPS * 2 * op.cout for op in prog.ops if op.bn)
+        sums_arena = torch.zeros(nsum, dtype=torch.float32, device=dev)
+        spos = [0]
+
+        def take_sums(c):
+            n = L.ACT_BWD_REPS * 2 * c
+            t = sums_arena[spos[0]:spos[0] + n]
+            spos[0] += n
+            return t
 
         for op in reversed(prog.ops):
             k = op.kind
@@ -283,6 +293,8 @@ class Executor:
                                 kw.update(mean=rm, invstd=istd, gamma=sd[op.bn + ".weight"])
                         if need_wgrad:
                             kw.update(dgamma=gr[op.bn + ".weight"], dbeta=gr[op.bn + ".bias"])
+                    if op.bn:
+                        kw["sums"] = take_sums(v.C)
                     ops.act_bwd(v, c or [], gout, g_pool=pl[0] if pl else None, pool_idx=pl[1] if pl else None, **kw)
                     g = Lazy(gout)
             # ---- this conv's own backward

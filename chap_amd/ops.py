@@ -195,7 +195,7 @@ def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=
         bn_mode = 1 if mean is not None else 0
     need_reduce = bn_mode == 1 or (bn_mode == 2 and (dgamma is not None or dbeta is not None))
     if need_reduce and sums is None:
-        sums = torch.zeros(2 * lazy.C, dtype=torch.float32, device=gout.device)
+        sums = torch.zeros(L.ACT_BWD_REPS * 2 * lazy.C, dtype=torch.float32, device=gout.device)
     p = _act_bwd_params(lazy, grads, g_pool, pool_idx, mean, invstd, gamma, sums, gout, dgamma, dbeta, count)
     p.bn = bn_mode
     if need_reduce:

@@ -33,6 +33,7 @@ extern "C" {
 #endif
 
 #define CHAP_ABI_VERSION 1
+#define CHAP_ACT_BWD_REPS 32   /* replicas of the BN-backward partial sums (spreads float atomics) */
 
 enum { CHAP_F32 = 0, CHAP_BF16 = 1 };
 enum { CHAP_OK = 0, CHAP_EINVAL = -1, CHAP_EUNSUPPORTED = -2, CHAP_ELAUNCH = -3 };
@@ -182,8 +183,8 @@ int chap_bn_eval_affine(const chap_bn_eval_params* p, void* stream);
  * routing] and training-mode BatchNorm, for one stored raw tensor r.
  *   phase 1 (reduce): dz = (sum of incoming dact grads) * da/dz;  sums[0][c] = sum dz,
  *                     sums[1][c] = sum dz * rhat              (rhat = (r-mean)*invstd)
+ *                     (then the replicas are compacted and dgamma += sums1, dbeta += sums0)
  *   phase 2 (apply):  g = gamma*invstd*(dz - sums0/cnt - rhat*sums1/cnt)  -> gout (dtype)
- *                     dgamma += sums1, dbeta += sums0
  * Incoming gradients: up to 3 same-grid tensors (ptr, ld, coff) and one half-resolution pooled
  * gradient routed through the saved arg-max index. With bn == 0 (no BatchNorm after the conv)
  * phase 2 writes g = dz and no sums are needed. */
@@ -192,7 +193,7 @@ typedef struct {
     const void* g_pool; const uint8_t* pool_idx;     /* [N][H/2][W/2][C] each, or NULL           */
     chap_src_t  r;                                   /* the raw tensor + its forward transform    */
     const float* mean; const float* invstd; const float* gamma;
-    float* sums;            /* [2][C] workspace, zeroed by the caller                             */
+    float* sums;            /* [CHAP_ACT_BWD_REPS][2][C] workspace, zeroed by the caller            */
     void*  gout;            /* [pixels][C] dtype                                                  */
     float* dgamma; float* dbeta;                     /* accumulated (+=)                          */
     int32_t N, D, H, W;  int32_t bn;  /* 0 none, 1 training-mode BN, 2 fixed affine (eval BN): g = dz*scale */
