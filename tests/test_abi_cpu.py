@@ -1,0 +1,132 @@
+"""CPU-only checks of the C-ABI boundary and the host-side mirror: the shared library loads and
+exports every symbol include/chap_hip.h declares (no compute calls), ctypes structure sizes match the
+header (via a compiled sizeof probe), and the drop-in modules reproduce the reference's state-dict
+keys/shapes and default initialisation."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "chap_hip.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|size_t|const char\*)\s+(chap_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from chap_amd import _lib
+    lib = _lib.lib()
+    names = _declared_functions()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.chap_abi_version() == 1
+    # every entry point bound in the ctypes tables is declared in the header and vice versa
+    bound = set(_lib._SIGS) | set(_lib._SIZE_FNS) | {"chap_last_error", "chap_abi_version", "chap_debug_copy"}
+    assert bound == set(names), (bound ^ set(names))
+
+
+def test_ctypes_struct_sizes_match_header(tmp_path):
+    """compile a tiny C program that prints sizeof() of every params struct and compare with ctypes."""
+    from chap_amd import _lib
+    pairs = {"chap_src_t": _lib.Src, "chap_conv_params": _lib.ConvParams, "chap_pack_params": _lib.PackParams,
+             "chap_conv_c1_params": _lib.ConvC1Params, "chap_conv_c1_bwd_params": _lib.ConvC1BwdParams,
+             "chap_wgrad_params": _lib.WgradParams, "chap_bn_finalize_params": _lib.BnFinalizeParams,
+             "chap_bn_eval_params": _lib.BnEvalParams, "chap_act_bwd_params": _lib.ActBwdParams,
+             "chap_pool_params": _lib.PoolParams, "chap_upsample_params": _lib.UpsampleParams,
+             "chap_upsample_bwd_params": _lib.UpsampleBwdParams, "chap_planar_to_cl_params": _lib.PlanarToClParams,
+             "chap_cl_to_planar_params": _lib.ClToPlanarParams, "chap_chansum_params": _lib.ChanSumParams,
+             "chap_mix_loss_params": _lib.MixLossParams, "chap_pseudo_params": _lib.PseudoParams, "chap_kl_params": _lib.KlParams,
+             "chap_l2norm_params": _lib.L2NormParams, "chap_axpy_params": _lib.AxpyParams, "chap_rand_params": _lib.RandParams,
+             "chap_keepmask_params": _lib.KeepMaskParams, "chap_chanmask_params": _lib.ChanMaskParams,
+             "chap_boxmix_params": _lib.BoxMixParams, "chap_boxmask_params": _lib.BoxMaskParams, "chap_lcc_params": _lib.LccParams,
+             "chap_diffmask_params": _lib.DiffMaskParams, "chap_sgd_params": _lib.SgdParams}
+    c = tmp_path / "sz.c"
+    body = "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in pairs)
+    c.write_text('#include <stdio.h>\n#include "chap_hip.h"\nint main(void){\n%sreturn 0;}\n' % body)
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    sizes = dict(line.split() for line in out.strip().splitlines())
+    for name, st in pairs.items():
+        assert int(sizes[name]) == ctypes.sizeof(st), (name, sizes[name], ctypes.sizeof(st))
+
+
+def test_errors_are_reported_not_swallowed():
+    from chap_amd import _lib
+    p = _lib.PackParams()           # null pointers -> CHAP_EINVAL with a message, no launch
+    with pytest.raises(_lib.ChapError, match="null"):
+        _lib.call("chap_pack_weights", p, 0)
+
+
+def test_state_dict_contract_2d(golden_dir):
+    from chap_amd.networks import DualDecoder, UNet
+    g = np.load(os.path.join(golden_dir, "dualdecoder2d_64.npz"))
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"})
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["keys"]) and [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert [n for n, _ in m.named_parameters()] == list(g["param_names"])
+    assert sum(p.numel() for p in m.parameters()) == 2577624
+    assert hasattr(m, "encoder") and hasattr(m, "decoder1") and hasattr(m, "decoder2")
+    # default initialisation draws the RNG exactly like the reference (seed 1337, train_ours_2D.py:487,551)
+    gi = np.load(os.path.join(golden_dir, "dualdecoder2d_init1337.npz"))
+    torch.manual_seed(1337)
+    md = DualDecoder(1, 4, {"decoder_type": "mcnet"})
+    chk = np.array([[float(t.double().sum()), float(t.double().abs().sum())] for t in md.state_dict().values()])
+    np.testing.assert_allclose(chk, gi["checks"], rtol=0, atol=0)
+    u = UNet(1, 4)
+    assert list(u.state_dict().keys()) == list(np.load(os.path.join(golden_dir, "unet2d_32.npz"))["keys"])
+    assert sum(p.numel() for p in u.parameters()) == 1813764
+
+
+def test_state_dict_contract_3d(golden_dir):
+    from chap_amd.networks import DualDecoder3d, VNet
+    g = np.load(os.path.join(golden_dir, "dualdecoder3d_32.npz"))
+    m = DualDecoder3d(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["keys"]) and [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert sum(p.numel() for p in m.parameters()) == 12347716
+    gi = np.load(os.path.join(golden_dir, "dualdecoder3d_init1337.npz"))
+    torch.manual_seed(1337)
+    md = DualDecoder3d(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)
+    chk = np.array([[float(t.double().sum()), float(t.double().abs().sum())] for t in md.state_dict().values()])
+    np.testing.assert_allclose(chk, gi["checks"], rtol=0, atol=0)
+    v = VNet(n_channels=1, n_classes=2, normalization="batchnorm")
+    assert list(v.state_dict().keys()) == list(np.load(os.path.join(golden_dir, "vnet_16.npz"))["keys"])
+    assert sum(p.numel() for p in v.parameters()) == 9448866
+
+
+def test_checkpoint_roundtrip_and_factory_semantics(tmp_path):
+    """torch.save(model.state_dict()) / load_state_dict(strict=True), as the reference's train/test scripts do."""
+    from chap_amd.networks import DualDecoder, net_factory
+    from oracle import init as oinit
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"})
+    state = oinit.dual_decoder_2d_state(5)
+    m.load_state_dict(state, strict=True)
+    path = tmp_path / "dualdecoder_best_model.pth"
+    torch.save(m.state_dict(), str(path))
+    m2 = DualDecoder(1, 4, {"decoder_type": "mcnet"})
+    m2.load_state_dict(torch.load(str(path), map_location="cpu"))
+    for k, v in state.items():
+        assert torch.equal(m2.state_dict()[k], v), k
+    with pytest.raises(RuntimeError):
+        m2.load_state_dict({"bogus": torch.zeros(1)})              # strict by default (test_2D_fully.py:117)
+    assert net_factory("no_such_net", device="cpu") is None        # reference returns None (net_factory.py:23)
+
+
+def test_host_schedules_match_oracle():
+    from chap_amd import train
+    from oracle import train_step as ots
+    for it in (0, 149, 150, 3000, 7499, 7500, 20000):
+        assert abs(train.get_current_consistency_weight(it // 150, train.DEFAULT_ARGS) - ots.consistency_weight(it)) < 1e-12
+    assert train.sigmoid_rampup(0, 0) == 1.0 and abs(train.sigmoid_rampup(50, 50) - 1.0) < 1e-12
+    assert abs(train.sigmoid_rampup(0, 50) - np.exp(-5.0)) < 1e-12
