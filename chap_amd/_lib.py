@@ -137,15 +137,15 @@ class ChanMaskParams(C.Structure):
 
 
 class BoxMixParams(C.Structure):
-    _fields_ = [("a", _vp), ("b", _vp), ("out", _vp), ("box", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("is_i64", _i32)]
+    _fields_ = [("a", _vp), ("b", _vp), ("out", _vp), ("box", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("is_i64", _i32), ("D", _i32)]
 
 
 class BoxMaskParams(C.Structure):
-    _fields_ = [("mask", _vp), ("box", _vp), ("N", _i32), ("H", _i32), ("W", _i32)]
+    _fields_ = [("mask", _vp), ("box", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("D", _i32)]
 
 
 class LccParams(C.Structure):
-    _fields_ = [("labels", _vp), ("out", _vp), ("ws", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("num_classes", _i32)]
+    _fields_ = [("labels", _vp), ("out", _vp), ("ws", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("num_classes", _i32), ("D", _i32)]
 
 
 class DiffMaskParams(C.Structure):

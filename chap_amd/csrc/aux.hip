@@ -84,39 +84,42 @@ extern "C" int chap_chan_mask(const chap_chanmask_params* p, void* stream) {
     return CHAP_OK;
 }
 
-// ---- BCP box mixing ----------------------------------------------------------------------------
+// ---- BCP box mixing (2D: box = {y0, x0, bh, bw}; 3D cuboid: box = {z0, y0, x0, bd, bh, bw}) ----------
+__device__ __forceinline__ bool in_box(const int32_t* box, int D, int z, int y, int x) {
+    if (D > 1) return z >= box[0] && z < box[0] + box[3] && y >= box[1] && y < box[1] + box[4] && x >= box[2] && x < box[2] + box[5];
+    return y >= box[0] && y < box[0] + box[2] && x >= box[1] && x < box[1] + box[3];
+}
 template <typename T>
-__global__ void boxmix_kernel(const T* a, const T* b, T* out, const int32_t* box, int N, int H, int W) {
-    const int y0 = box[0], x0 = box[1], bh = box[2], bw = box[3];
-    const long total = (long)N * H * W;
+__global__ void boxmix_kernel(const T* a, const T* b, T* out, const int32_t* box, int N, int D, int H, int W) {
+    const long total = (long)N * D * H * W;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % W), y = (int)((i / W) % H);
-        const bool inside = y >= y0 && y < y0 + bh && x >= x0 && x < x0 + bw;
-        out[i] = inside ? b[i] : a[i];
+        const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)((i / ((long)W * H)) % D);
+        out[i] = in_box(box, D, z, y, x) ? b[i] : a[i];
     }
 }
 extern "C" int chap_box_mix(const chap_boxmix_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->a && p->b && p->out && p->box, "chap_box_mix: null argument");
-    const long total = (long)p->N * p->H * p->W;
+    const int D = p->D > 1 ? p->D : 1;
+    const long total = (long)p->N * D * p->H * p->W;
     const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    if (p->is_i64) hipLaunchKernelGGL(boxmix_kernel<int64_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const int64_t*)p->a, (const int64_t*)p->b, (int64_t*)p->out, p->box, p->N, p->H, p->W);
-    else hipLaunchKernelGGL(boxmix_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)p->a, (const float*)p->b, (float*)p->out, p->box, p->N, p->H, p->W);
+    if (p->is_i64) hipLaunchKernelGGL(boxmix_kernel<int64_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const int64_t*)p->a, (const int64_t*)p->b, (int64_t*)p->out, p->box, p->N, D, p->H, p->W);
+    else hipLaunchKernelGGL(boxmix_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)p->a, (const float*)p->b, (float*)p->out, p->box, p->N, D, p->H, p->W);
     CHAP_LAUNCH_CHECK("chap_box_mix");
     return CHAP_OK;
 }
-__global__ void boxmask_kernel(const chap_boxmask_params P) {
-    const int y0 = P.box[0], x0 = P.box[1], bh = P.box[2], bw = P.box[3];
-    const long total = (long)P.N * P.H * P.W;
+__global__ void boxmask_kernel(const chap_boxmask_params P, int D) {
+    const long total = (long)P.N * D * P.H * P.W;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % P.W), y = (int)((i / P.W) % P.H);
-        P.mask[i] = (y >= y0 && y < y0 + bh && x >= x0 && x < x0 + bw) ? 0 : 1;
+        const int x = (int)(i % P.W), y = (int)((i / P.W) % P.H), z = (int)((i / ((long)P.W * P.H)) % D);
+        P.mask[i] = in_box(P.box, D, z, y, x) ? 0 : 1;
     }
 }
 extern "C" int chap_box_mask(const chap_boxmask_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->mask && p->box, "chap_box_mask: null argument");
-    const long total = (long)p->N * p->H * p->W;
+    const int D = p->D > 1 ? p->D : 1;
+    const long total = (long)p->N * D * p->H * p->W;
     const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(boxmask_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(boxmask_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p, D);
     CHAP_LAUNCH_CHECK("chap_box_mask");
     return CHAP_OK;
 }

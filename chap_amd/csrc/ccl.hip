@@ -28,19 +28,22 @@ __global__ void lcc_init_kernel(const int64_t* lab, int* L, unsigned* size, unsi
     }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nbest; i += (long)gridDim.x * blockDim.x) best[i] = 0ull;
 }
-__global__ void lcc_merge_kernel(const int64_t* lab, int* L, int N, int H, int W) {
-    const long total = (long)N * H * W;
+__global__ void lcc_merge_kernel(const int64_t* lab, int* L, int N, int D, int H, int W) {
+    const long total = (long)N * D * H * W;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int64_t c = lab[i];
         if (c <= 0) continue;
-        const int x = (int)(i % W), y = (int)((i / W) % H);
-        // forward neighbours: E, SW, S, SE (each undirected edge visited once)
-        if (x + 1 < W && lab[i + 1] == c) uf_union(L, (int)i, (int)i + 1);
-        if (y + 1 < H) {
-            if (x > 0 && lab[i + W - 1] == c) uf_union(L, (int)i, (int)(i + W - 1));
-            if (lab[i + W] == c) uf_union(L, (int)i, (int)(i + W));
-            if (x + 1 < W && lab[i + W + 1] == c) uf_union(L, (int)i, (int)(i + W + 1));
-        }
+        const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)((i / ((long)W * H)) % D);
+        // "forward" half of the 8- (2D) / 26- (3D) neighbourhood: each undirected edge is visited once
+        for (int dz = 0; dz <= (D > 1 ? 1 : 0); ++dz)
+            for (int dy = (dz ? -1 : 0); dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (dz == 0 && (dy < 0 || (dy == 0 && dx <= 0))) continue;
+                    const int zz = z + dz, yy = y + dy, xx = x + dx;
+                    if (zz >= D || yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                    const long q = i + ((long)dz * H + dy) * W + dx;
+                    if (lab[q] == c) uf_union(L, (int)i, (int)q);
+                }
     }
 }
 __global__ void lcc_count_kernel(int* L, unsigned* size, long total) {
@@ -76,12 +79,13 @@ __global__ void lcc_write_kernel(const int64_t* lab, const int* L, const unsigne
 
 extern "C" size_t chap_lcc_ws(const chap_lcc_params* p) {
     if (!p) return 0;
-    const size_t total = (size_t)p->N * p->H * p->W;
+    const size_t total = (size_t)p->N * (p->D > 1 ? p->D : 1) * p->H * p->W;
     return total * (sizeof(int) + sizeof(unsigned)) + ((size_t)p->N * p->num_classes + 8) * sizeof(unsigned long long) + 64;
 }
 extern "C" int chap_largest_cc(const chap_lcc_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->labels && p->out && p->ws, "chap_largest_cc: null argument");
-    const long total = (long)p->N * p->H * p->W;
+    const int D = p->D > 1 ? p->D : 1;
+    const long total = (long)p->N * D * p->H * p->W;
     CHAP_CHECK_ARG(total < 0x7FFFFFFFL, "chap_largest_cc: too many pixels");
     hipStream_t s = (hipStream_t)stream;
     const int nbest = p->N * p->num_classes;
@@ -90,10 +94,10 @@ extern "C" int chap_largest_cc(const chap_lcc_params* p, void* stream) {
     unsigned* size = (unsigned*)(L + total);
     const int nb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(lcc_init_kernel, dim3(nb), dim3(256), 0, s, p->labels, L, size, best, total, nbest);
-    hipLaunchKernelGGL(lcc_merge_kernel, dim3(nb), dim3(256), 0, s, p->labels, L, p->N, p->H, p->W);
+    hipLaunchKernelGGL(lcc_merge_kernel, dim3(nb), dim3(256), 0, s, p->labels, L, p->N, D, p->H, p->W);
     hipLaunchKernelGGL(lcc_count_kernel, dim3(nb), dim3(256), 0, s, L, size, total);
-    hipLaunchKernelGGL(lcc_best_kernel, dim3(nb), dim3(256), 0, s, p->labels, (const int*)L, (const unsigned*)size, best, p->H * p->W, p->num_classes, total);
-    hipLaunchKernelGGL(lcc_write_kernel, dim3(nb), dim3(256), 0, s, p->labels, (const int*)L, (const unsigned long long*)best, p->out, p->H * p->W, p->num_classes, total);
+    hipLaunchKernelGGL(lcc_best_kernel, dim3(nb), dim3(256), 0, s, p->labels, (const int*)L, (const unsigned*)size, best, D * p->H * p->W, p->num_classes, total);
+    hipLaunchKernelGGL(lcc_write_kernel, dim3(nb), dim3(256), 0, s, p->labels, (const int*)L, (const unsigned long long*)best, p->out, D * p->H * p->W, p->num_classes, total);
     CHAP_LAUNCH_CHECK("chap_largest_cc");
     return CHAP_OK;
 }

@@ -315,21 +315,25 @@ def box_mix(a, b, out, box):
     p = L.BoxMixParams()
     p.a, p.b, p.out, p.box = a.data_ptr(), b.data_ptr(), out.data_ptr(), box.data_ptr()
     p.N, p.H, p.W, p.is_i64 = a.shape[0], a.shape[-2], a.shape[-1], int(a.dtype == torch.int64)
+    p.D = a.shape[-3] if box.numel() == 6 else 1
     L.call("chap_box_mix", p, _stream())
 
 
 def box_mask(mask, box):
     p = L.BoxMaskParams()
     p.mask, p.box, p.N, p.H, p.W = mask.data_ptr(), box.data_ptr(), mask.shape[0], mask.shape[-2], mask.shape[-1]
+    p.D = mask.shape[-3] if box.numel() == 6 else 1
     L.call("chap_box_mask", p, _stream())
 
 
 def largest_cc(labels, num_classes):
-    """labels int64 [N, H, W] -> int64 [N, H, W] keeping the largest 8-connected component per class."""
+    """labels int64 [N, H, W] (8-connectivity) or [N, D, H, W] (26-connectivity) -> same shape, keeping the
+    largest connected component per (sample, class > 0)."""
     out = torch.empty_like(labels)
     p = L.LccParams()
     p.labels, p.out = labels.data_ptr(), out.data_ptr()
-    p.N, p.H, p.W, p.num_classes = labels.shape[0], labels.shape[1], labels.shape[2], num_classes
+    p.N, p.H, p.W, p.num_classes = labels.shape[0], labels.shape[-2], labels.shape[-1], num_classes
+    p.D = labels.shape[1] if labels.dim() == 4 else 1
     ws = torch.empty(L.size_of("chap_lcc_ws", p), dtype=torch.uint8, device=labels.device)
     p.ws = ws.data_ptr()
     L.call("chap_largest_cc", p, _stream())
@@ -337,6 +341,10 @@ def largest_cc(labels, num_classes):
 
 
 def diff_mask(p1, p2, knowledge, scale, topk):
+    """[N, H, W] maps (3D volumes are passed as [N, D*H, W]: in-plane scale x scale patches)."""
+    if knowledge.dim() == 4:
+        n, d, h, w = knowledge.shape
+        return diff_mask(p1.reshape(n, d * h, w), p2.reshape(n, d * h, w), knowledge.reshape(n, d * h, w), scale, topk).reshape(n, d, h, w)
     N, H, W = knowledge.shape
     out = torch.empty(N, H, W, dtype=torch.float32, device=knowledge.device)
     ws = torch.empty(N, H // scale, W // scale, dtype=torch.float32, device=knowledge.device)

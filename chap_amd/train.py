@@ -105,9 +105,11 @@ class VAT2d:
 
 
 class ChapStep:
-    """One iteration of train() (train_ours_2D.py:301-389) for a DualDecoder on 2D slices.
+    """One iteration of train() (train_ours_2D.py:301-389) for a DualDecoder on 2D slices, or -- the
+    same loop restated on 5-D tensors, the reference has no 3D training script -- a DualDecoder3d on
+    volumes (cuboid BCP box, 26-connected largest component, in-plane 4x4 patches for the VAT mask).
 
-    step(volume_batch [B,1,H,W] fp32, label_batch [B,H,W] int64) -> dict of device scalars.
+    step(volume_batch [B,1,*sp] fp32, label_batch [B,*sp] int64) -> dict of device scalars.
     The BCP box offsets, LR and consistency weight live in device memory so that the whole iteration
     can be captured once as a HIP graph (`capture()`) and replayed."""
 
@@ -118,7 +120,8 @@ class ChapStep:
         self.opt = optimizer or FusedSGD(model, a["base_lr"], a["momentum"], a["weight_decay"])
         self.adv_loss = VAT2d(xi=a["noise_mag"], epi=a["epi"], num_classes=a["num_classes"], ip=a["vat_iters"], sign=a["vat_sign"])
         dev = self.opt.lr_dev.device
-        self.box = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.dims = getattr(model, "dims", 2)
+        self.box = torch.zeros(4 if self.dims == 2 else 6, dtype=torch.int32, device=dev)
         self.cw_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.iter_num = 0
         self.world_size = world_size
@@ -130,11 +133,10 @@ class ChapStep:
         """Host work of an iteration that must happen BEFORE the device work (and outside a captured
         graph): BCP box offsets (np.random.randint, train_ours_2D.py:97-98), consistency weight."""
         a = self.args
-        H, W = self._hw
-        ph, pw = int(H * 2 / 3), int(W * 2 / 3)
+        sizes = [int(s * 2 / 3) for s in self._hw]                 # patch = 2/3 of every side (:96)
         if box_yx is None:
-            box_yx = (np.random.randint(0, H - ph), np.random.randint(0, W - pw))
-        self.box.copy_(torch.tensor([box_yx[0], box_yx[1], ph, pw], dtype=torch.int32))
+            box_yx = tuple(np.random.randint(0, s - p) for s, p in zip(self._hw, sizes))
+        self.box.copy_(torch.tensor(list(box_yx) + sizes, dtype=torch.int32))
         self.cw_dev.fill_(get_current_consistency_weight(self.iter_num // 150, a))
 
     def finish(self):
@@ -214,7 +216,7 @@ class ChapStep:
         return {"mix_losses": losses, "vat_loss": vat_loss}
 
     def step(self, volume_batch, label_batch, box_yx=None, inject=None):
-        self._hw = tuple(volume_batch.shape[-2:])
+        self._hw = tuple(volume_batch.shape[2:])
         self.prepare(box_yx)
         out = self.device_step(volume_batch, label_batch, inject)
         self.finish()
@@ -224,7 +226,7 @@ class ChapStep:
     def capture(self, volume_batch, label_batch, warmup=3):
         """Capture device_step() into one HIP graph over static input buffers; afterwards call
         replay(volume_batch, label_batch)."""
-        self._hw = tuple(volume_batch.shape[-2:])
+        self._hw = tuple(volume_batch.shape[2:])
         self._static_v = volume_batch.clone()
         self._static_l = label_batch.clone()
         s = torch.cuda.Stream()

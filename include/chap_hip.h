@@ -281,15 +281,15 @@ int chap_chan_mask(const chap_chanmask_params* p, void* stream);     /* mul[i] =
 
 /* BCP copy-paste mixing (train_ours_2D.py:91-101, 331-338). box = device int32[4] {y0, x0, bh, bw}:
  * out = inside box ? b : a  (mask is 0 inside the box: a*mask + b*(1-mask)). */
-typedef struct { const void* a; const void* b; void* out; const int32_t* box; int32_t N, H, W; int32_t is_i64; } chap_boxmix_params;
+typedef struct { const void* a; const void* b; void* out; const int32_t* box; int32_t N, H, W; int32_t is_i64; int32_t D; } chap_boxmix_params;  /* D > 1: 3D cuboid, box = {z0,y0,x0,bd,bh,bw} */
 int chap_box_mix(const chap_boxmix_params* p, void* stream);
-typedef struct { int64_t* mask; const int32_t* box; int32_t N, H, W; } chap_boxmask_params;
+typedef struct { int64_t* mask; const int32_t* box; int32_t N, H, W, D; } chap_boxmask_params;
 int chap_box_mask(const chap_boxmask_params* p, void* stream);       /* loss_mask: 0 inside the box, 1 outside */
 
 /* Largest connected component per (image, class>0), 8-connectivity (skimage.measure.label default),
  * get_ACDC_2DLargestCC (train_ours_2D.py:123-144) without the 72 device->host round trips.
  * labels/out: int64 [N][H][W]; ws: chap_lcc_ws() bytes. Ties: the component met first in raster order. */
-typedef struct { const int64_t* labels; int64_t* out; void* ws; int32_t N, H, W, num_classes; } chap_lcc_params;
+typedef struct { const int64_t* labels; int64_t* out; void* ws; int32_t N, H, W, num_classes; int32_t D; /* D > 1: volumes, 26-connectivity */ } chap_lcc_params;
 size_t chap_lcc_ws(const chap_lcc_params* p);
 int    chap_largest_cc(const chap_lcc_params* p, void* stream);
 

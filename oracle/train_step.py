@@ -77,12 +77,21 @@ def box_masks(n, h, w, y0, x0, dtype=torch.float32):
     return mask, mask.unsqueeze(0).repeat(n, 1, 1)
 
 
+def box_masks_3d(n, d, h, w, z0, y0, x0, dtype=torch.float32):
+    """3D restatement of generate_mask (the reference has no 3D loop): zero cuboid of 2/3 of each side."""
+    pd, ph, pw = int(d * 2 / 3), int(h * 2 / 3), int(w * 2 / 3)
+    mask = torch.ones(d, h, w, dtype=dtype)
+    mask[z0:z0 + pd, y0:y0 + ph, x0:x0 + pw] = 0
+    return mask, mask.unsqueeze(0).repeat(n, 1, 1, 1)
+
+
 def largest_cc(seg, n_classes):
-    """seg int [N,H,W] -> keep, per sample and class 1..C-1, the largest 8-connected component."""
+    """seg int [N,H,W] / [N,D,H,W] -> keep, per sample and class 1..C-1, the largest component
+    (full connectivity: 8 in 2D, 26 in 3D -- skimage.measure.label's default)."""
     from scipy import ndimage
     seg = seg.cpu().numpy()
     out = np.zeros_like(seg)
-    full = np.ones((3, 3), dtype=bool)
+    full = np.ones((3,) * (seg.ndim - 1), dtype=bool)
     for i in range(seg.shape[0]):
         for c in range(1, n_classes):
             lab, n = ndimage.label(seg[i] == c, structure=full)
@@ -101,7 +110,11 @@ def pseudo_block(pre1, pre2):
 
 
 def create_mask_v1(p1, p2, knowledge, scale_factor=4, topk=0.1):
-    """(p1 != p2) OR nearest-upsample(top-k fraction of avg_pool(knowledge, scale)) -> float [N,H,W]."""
+    """(p1 != p2) OR nearest-upsample(top-k fraction of avg_pool(knowledge, scale)) -> float [N,H,W].
+    Volumes [N,D,H,W] are treated as [N, D*H, W] (in-plane scale x scale patches, top-k per sample)."""
+    if knowledge.dim() == 4:
+        n, d, h, w = knowledge.shape
+        return create_mask_v1(p1.reshape(n, d * h, w), p2.reshape(n, d * h, w), knowledge.reshape(n, d * h, w), scale_factor, topk).reshape(n, d, h, w)
     n, h, w = knowledge.shape
     pooled = F.avg_pool2d(knowledge.unsqueeze(1), scale_factor).squeeze(1).clamp_min(0)
     m = pooled[0].numel()
@@ -179,13 +192,13 @@ def iteration(sd, moms, volume_batch, label_batch, box_yx, iter_num, lr, args=No
     uimg_a, uimg_b = volume_batch[lbs:lbs + usub], volume_batch[lbs + usub:]
     lab_a, lab_b = label_batch[:lsub], label_batch[lsub:lbs]
     uimg_ab = volume_batch[lbs:]
-    H, W = volume_batch.shape[-2:]
+    sp = tuple(volume_batch.shape[2:])
     with torch.no_grad():
         pre1, pre2 = net(sd, uimg_ab, train=True, drop=inject.get("drop_A"))
         soft1, soft2, arg1, arg2, know = pseudo_block(pre1, pre2)
         plab1 = largest_cc(arg1, nc) if a["nms"] else arg1
         plab2 = largest_cc(arg2, nc) if a["nms"] else arg2
-        img_mask, loss_mask = box_masks(lsub, H, W, box_yx[0], box_yx[1])
+        img_mask, loss_mask = (box_masks(lsub, *sp, *box_yx) if len(sp) == 2 else box_masks_3d(lsub, *sp, *box_yx))
         net_input_unl = uimg_a * img_mask + img_a * (1 - img_mask)
         net_input_l = img_b * img_mask + uimg_b * (1 - img_mask)
         net_input_mix = torch.cat((net_input_l, net_input_unl))
@@ -245,4 +258,28 @@ def synthetic_batch(seed, n_lab, n_unlab, h, w, n_classes=4):
         for c in range(1, n_classes):
             lab[main > (0.25 + 0.5 * c / n_classes)] = c
         labs[i] = lab
+    return imgs, labs
+
+
+def synthetic_batch_3d(seed, n_lab, n_unlab, d, h, w):
+    """Fixed-seed synthetic volumes (LA-like, 2 classes): one anisotropic Gaussian blob = foreground."""
+    g = torch.Generator().manual_seed(seed)
+    n = n_lab + n_unlab
+    zz, yy, xx = torch.meshgrid(torch.arange(d, dtype=torch.float32), torch.arange(h, dtype=torch.float32),
+                                torch.arange(w, dtype=torch.float32), indexing="ij")
+    imgs = torch.zeros(n, 1, d, h, w)
+    labs = torch.zeros(n, d, h, w, dtype=torch.int64)
+    dims = torch.tensor([d, h, w], dtype=torch.float32)
+    for i in range(n):
+        c = (0.35 + 0.3 * torch.rand(3, generator=g)) * dims
+        s = (0.12 + 0.1 * torch.rand(3, generator=g)) * dims
+        main = torch.exp(-(((zz - c[0]) / s[0]) ** 2 + ((yy - c[1]) / s[1]) ** 2 + ((xx - c[2]) / s[2]) ** 2))
+        img = main.clone()
+        for _ in range(2):
+            b = torch.rand(3, generator=g) * dims
+            bs = (0.05 + 0.1 * torch.rand(1, generator=g)) * d
+            img += 0.5 * torch.rand(1, generator=g) * torch.exp(-(((zz - b[0]) / bs) ** 2 + ((yy - b[1]) / bs) ** 2 + ((xx - b[2]) / bs) ** 2))
+        img += 0.05 * torch.randn(d, h, w, generator=g)
+        imgs[i, 0] = (img - img.min()) / (img.max() - img.min() + 1e-8)
+        labs[i] = (main > 0.5).long()
     return imgs, labs

@@ -232,3 +232,26 @@ def test_lcc_diffmask_vat_helpers_sgd():
     assert relerr(pd, params[0]) < 1e-6 and relerr(md, moms[0]) < 1e-6
     ops.sgd_step(pd, gd, md, lr, 0.9, 1e-4, zero_grad=True)
     assert gd.abs().max().item() == 0
+
+
+def test_lcc_and_box_3d():
+    g = torch.Generator().manual_seed(17)
+    N, D, H, W = 3, 12, 20, 24
+    z = F.avg_pool3d(torch.randn(N, 3, D + 4, H + 4, W + 4, generator=g), 5, stride=1)
+    lab = z.argmax(1)
+    lab[0] = 0
+    ref = ots.largest_cc(lab, 3)
+    got = ops.largest_cc(lab.to(DEV), 3)
+    assert (got.cpu() == ref).all()
+    box = torch.tensor([1, 3, 5, int(D * 2 / 3), int(H * 2 / 3), int(W * 2 / 3)], dtype=torch.int32, device=DEV)
+    mask, lm = ots.box_masks_3d(N, D, H, W, 1, 3, 5)
+    a, b = torch.rand(N, 1, D, H, W, generator=g), torch.rand(N, 1, D, H, W, generator=g)
+    o = torch.empty_like(a, device=DEV)
+    ops.box_mix(a.to(DEV), b.to(DEV), o, box)
+    assert relerr(o, a * mask + b * (1 - mask)) < 1e-7
+    lmd = torch.empty(N, D, H, W, dtype=torch.int64, device=DEV)
+    ops.box_mask(lmd, box)
+    assert (lmd.cpu() == lm.long()).all()
+    kn = torch.rand(N, D, H, W, generator=g) * 3
+    p1, p2 = lab, torch.roll(lab, 1, 3)
+    assert (ops.diff_mask(p1.to(DEV), p2.to(DEV), kn.to(DEV), 4, 0.1).cpu() == ots.create_mask_v1(p1, p2, kn, 4, 0.1)).all()

@@ -82,3 +82,44 @@ def test_graph_capture_replay_runs():
     after = m.flat_buffers()[0]
     assert torch.isfinite(after).all() and (after - before).abs().max() > 0
     assert all(torch.isfinite(l).all() for l in out["mix_losses"]) and torch.isfinite(out["vat_loss"]).all()
+
+
+def test_iteration_3d_matches_oracle():
+    """The same loop on 5-D tensors (DualDecoder3d, 2 classes, cuboid BCP box, 26-connected LCC)."""
+    from chap_amd.networks import DualDecoder3d
+    from oracle import nets as onets
+    B, lbs, D, H, W = 4, 2, 16, 32, 16
+    U = B - lbs
+    args = dict(labeled_bs=lbs, batch_size=B, vat_iters=1, num_classes=2)
+    state = oinit.dual_decoder_3d_state(401)
+    vol, lab = ots.synthetic_batch_3d(1337, lbs, U, D, H, W)
+    dm = lambda seed, n: oinit.drop_masks_3d(seed, n)
+    inj_cpu = {"drop_A": dm(1, U), "drop_B": dm(2, lbs // 2 + U // 2), "drop_V0": dm(3, U), "drop_VF": dm(4, U),
+               "d0": torch.rand(U, 1, D, H, W, generator=torch.Generator().manual_seed(5)) - 0.5}
+    box = (2, 5, 3)
+    sd = {k: v.clone() for k, v in state.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    moms = {k: torch.zeros_like(v) for k, v in sd.items() if v.requires_grad}
+    ref = ots.iteration(sd, moms, vol, lab, box, iter_num=0, lr=0.01, args=args, inject=inj_cpu, net=onets.dual_decoder_3d)
+    m = DualDecoder3d(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True).to(DEV).train()
+    m.load_state_dict(state, strict=True)
+    step = ChapStep(m, args)
+    inj = {k: ({kk: (vv.float() * 2.0).to(DEV) for kk, vv in v.items()} if k.startswith("drop") else v.to(DEV)) for k, v in inj_cpu.items()}
+    out = step.step(vol.to(DEV), lab.to(DEV), box_yx=box, inject=inj)
+    torch.cuda.synchronize()
+    for got, want in zip(out["mix_losses"], ref["losses"]):
+        assert relerr(got.cpu(), torch.stack([w.detach() for w in want])) < 5e-4
+    assert relerr(out["vat_loss"].cpu(), ref["vat_loss"].reshape(1)) < 1e-2
+    after = m.state_dict()
+    worst, worst_key = 0.0, None
+    for k, v in sd.items():
+        if not v.is_floating_point():
+            continue
+        d = (after[k].cpu().double() - v.detach().double()).abs().max().item()
+        upd = (v.detach().double() - state[k].double()).abs().max().item()
+        floor = 3e-7 * v.detach().abs().max().item()
+        if upd > 0 and max(d - floor, 0.0) / upd > worst:
+            worst, worst_key = max(d - floor, 0.0) / upd, k
+    assert worst < 0.1, (worst, worst_key)
