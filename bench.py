@@ -26,6 +26,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 # ideal-fusion algorithmic bytes per training volume = (3.5 + K) * Bf
 BF_2D = {"bf16": 66.7e6, "fp32": 133.4e6}
 F_2D = 9.868e9                  # forward FLOPs per 256x256 slice
+BF_3D = {"bf16": 611.6e6, "fp32": 1223.3e6}     # per 112x112x80 patch
+F_3D = 175.66e9
 
 
 def parse():
@@ -33,10 +35,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="2d", choices=["2d"])
+    ap.add_argument("--config", default="2d", choices=["2d", "3d"])
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=24)
-    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=0, help="default 24 (2d) / 4 (3d)")
+    ap.add_argument("--size", type=int, default=256, help="2d: H = W")
+    ap.add_argument("--size3d", type=int, nargs=3, default=[112, 112, 80])
     ap.add_argument("--vat-iters", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -60,29 +63,37 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(args, B, H):
+def cpu_baseline(args, B, sp):
     """The oracle (CPU restatement, 'port') timed on this box's host cores on the same workload."""
     from oracle import init as oinit
+    from oracle import nets as onets
     from oracle import train_step as ots
     ncores = usable_cores()
     torch.set_num_threads(ncores)
     log("cpu_baseline: %d threads" % ncores)
-    state = oinit.dual_decoder_2d_state(1337)
+    d3 = len(sp) == 3
+    state = oinit.dual_decoder_3d_state(1337) if d3 else oinit.dual_decoder_2d_state(1337)
     sd = {k: v.clone() for k, v in state.items()}
     for k, v in sd.items():
         if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
             v.requires_grad_(True)
     moms = {k: torch.zeros_like(v) for k, v in sd.items() if v.requires_grad}
-    vol, lab = ots.synthetic_batch(1337, B // 2, B - B // 2, H, H)
-    a = dict(labeled_bs=B // 2, vat_iters=args.vat_iters)
-    ots.iteration(sd, moms, vol, lab, (10, 20), 0, 0.01, args=a)          # warm-up
+    if d3:
+        vol, lab = ots.synthetic_batch_3d(1337, B // 2, B - B // 2, *sp)
+        a = dict(labeled_bs=B // 2, vat_iters=args.vat_iters, num_classes=2)
+        net, box, iters = onets.dual_decoder_3d, (5, 6, 7), 1
+    else:
+        vol, lab = ots.synthetic_batch(1337, B // 2, B - B // 2, *sp)
+        a = dict(labeled_bs=B // 2, vat_iters=args.vat_iters)
+        net, box, iters = onets.dual_decoder_2d, (10, 20), args.cpu_iters
+    ots.iteration(sd, moms, vol, lab, box, 0, 0.01, args=a, net=net)          # warm-up
     log("cpu_baseline: warm-up iteration done")
     t0 = time.perf_counter()
-    for i in range(args.cpu_iters):
-        ots.iteration(sd, moms, vol, lab, (10 + i, 20), i + 1, 0.01, args=a)
+    for i in range(iters):
+        ots.iteration(sd, moms, vol, lab, box, i + 1, 0.01, args=a, net=net)
     dt = time.perf_counter() - t0
-    return {"value": B * args.cpu_iters / dt, "unit": "volumes/s", "cores": ncores, "kind": "port",
-            "sample": "%d iterations of the same bs=%d %dx%d iteration (oracle/train_step.py, fp32, torch CPU)" % (args.cpu_iters, B, H, H)}
+    return {"value": B * iters / dt, "unit": "volumes/s", "cores": ncores, "kind": "port",
+            "sample": "%d iteration(s) of the same bs=%d %s iteration (oracle/train_step.py, fp32, torch CPU)" % (iters, B, "x".join(map(str, sp)))}
 
 
 def dominant_kernel_roofline(model, dtype, N, H):
@@ -120,6 +131,41 @@ def dominant_kernel_roofline(model, dtype, N, H):
             "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": alg_bytes}
 
 
+def dominant_kernel_roofline_3d(dtype, N, sp):
+    """3D: the 16->16 3^3 conv at full resolution (block_nine / its dgrad), KC=16, NT=1."""
+    from chap_amd import _lib as L
+    from chap_amd import ops
+    dev = torch.device("cuda")
+    D, H, W = sp
+    x = torch.randn(N, D, H, W, 16, device=dev).to(dtype)
+    out = torch.empty_like(x)
+    w = torch.randn(16, 16, 3, 3, 3, device=dev) / 20
+    scale, shift = torch.rand(16, device=dev) + 0.5, torch.randn(16, device=dev) * 0.1
+    stats = torch.zeros(8, 2, 16, device=dev)
+    wp = ops.pack_weights(w, L.PACK_CONV_FWD, dtype, 16, 16, 27)
+    src = ops.Lazy(x, scale, shift, True, 0.0)
+
+    def launch():
+        ops.conv_fwd([src], wp, None, 16, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=3, stats=stats, stats_reps=8)
+
+    for _ in range(3):
+        launch()
+    reps = 20
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    esz = 2 if dtype == torch.bfloat16 else 4
+    alg_bytes = 2.0 * N * D * H * W * 16 * esz
+    ach = alg_bytes / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "traffic": None, "kernel": "conv_fwd_kernel<%s,3,1,3D,KC16,NT1> 16->16 @%dx%dx%d N=%d" % ("bf16" if esz == 2 else "f32", D, H, W, N),
+            "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": alg_bytes}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -135,22 +181,32 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
-    from chap_amd.networks import DualDecoder
+    from chap_amd.networks import DualDecoder, DualDecoder3d
     from chap_amd.train import ChapStep
     from oracle import train_step as ots   # synthetic data generator only (data, not the checker)
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    B, H = args.batch, args.size
+    d3 = args.config == "3d"
+    B = args.batch or (4 if d3 else 24)
+    H = args.size
+    sp = tuple(args.size3d) if d3 else (H, H)
     torch.manual_seed(1337)
-    model = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(dev).train().set_compute_dtype(dtype)
-    step = ChapStep(model, dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters), world_size=world)
+    if d3:
+        model = DualDecoder3d(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True).to(dev).train().set_compute_dtype(dtype)
+        step = ChapStep(model, dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters, num_classes=2), world_size=world)
+    else:
+        model = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(dev).train().set_compute_dtype(dtype)
+        step = ChapStep(model, dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters), world_size=world)
     if world > 1:
         from chap_amd.parallel import DataParallelSync
         step.grad_sync = DataParallelSync(model, dist)
-    vol, lab = ots.synthetic_batch(1337 + rank, B // 2, B - B // 2, H, H)    # each rank: its own shard (weak scaling)
+    if d3:
+        vol, lab = ots.synthetic_batch_3d(1337 + rank, B // 2, B - B // 2, *sp)
+    else:
+        vol, lab = ots.synthetic_batch(1337 + rank, B // 2, B - B // 2, H, H)    # each rank: its own shard (weak scaling)
     vol, lab = vol.to(dev), lab.to(dev)
     use_graph = (not args.no_graph) and world == 1
-    log("model + data ready (B=%d, %dx%d, %s)" % (B, H, H, args.dtype))
+    log("model + data ready (B=%d, %s, %s)" % (B, "x".join(map(str, sp)), args.dtype))
     if use_graph:
         step.capture(vol, lab, warmup=2)
         log("graph captured")
@@ -179,19 +235,27 @@ def main():
     vps = B * world * args.steps / dt
     if rank == 0:
         K = args.vat_iters
-        bytes_per_vol = (3.5 + K) * BF_2D[args.dtype] * (H * H) / (256 * 256)
-        flops_per_vol = (3.5 + K) * F_2D * (H * H) / (256 * 256)
-        roof = dominant_kernel_roofline(model, dtype, B // 2, H)
+        if d3:
+            vox = sp[0] * sp[1] * sp[2] / (112.0 * 112 * 80)
+            bytes_per_vol = (3.5 + K) * BF_3D[args.dtype] * vox
+            flops_per_vol = (3.5 + K) * F_3D * vox
+            roof = dominant_kernel_roofline_3d(dtype, B // 2, sp)
+        else:
+            bytes_per_vol = (3.5 + K) * BF_2D[args.dtype] * (H * H) / (256 * 256)
+            flops_per_vol = (3.5 + K) * F_2D * (H * H) / (256 * 256)
+            roof = dominant_kernel_roofline(model, dtype, B // 2, H)
         roof["iteration_hbm_frac_vs_ideal_fusion"] = round(vps / world * bytes_per_vol / 1e9 / HBM_PEAK_GBS, 4)
         roof["iteration_tflops"] = round(vps / world * flops_per_vol / 1e12, 2)
-        line = {"metric": "training volumes/sec (2D 256^2 bs24)", "value": round(vps, 2), "unit": "volumes/s", "n_gpus": world,
+        wl = ("LA 3D DualDecoder3d (V-Net) bs=%d (%d lab + %d unlab) %s patches, %d perturb step(s), N_v=U" % (B, B // 2, B - B // 2, "x".join(map(str, sp)), K)) if d3 else \
+             ("ACDC 2D DualDecoder bs=%d (%d lab + %d unlab) %dx%d, %d perturb step(s), N_v=U" % (B, B // 2, B - B // 2, H, H, K))
+        line = {"metric": "training volumes/sec (%s)" % ("3D 112x112x80 bs4" if d3 else "2D 256^2 bs24"), "value": round(vps, 2), "unit": "volumes/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-                "config": {"workload": "ACDC 2D DualDecoder bs=%d (%d lab + %d unlab) %dx%d, %d perturb step(s), N_v=U" % (B, B // 2, B - B // 2, H, H, K),
+                "config": {"workload": wl,
                            "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": use_graph, "losses_finite": finite},
                 "roofline": roof}
         if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args, B, H)
+            line["cpu_baseline"] = cpu_baseline(args, B, sp)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
