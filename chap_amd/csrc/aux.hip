@@ -93,7 +93,8 @@ template <typename T>
 __global__ void boxmix_kernel(const T* a, const T* b, T* out, const int32_t* box, int N, int D, int H, int W) {
     const long total = (long)N * D * H * W;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)((i / ((long)W * H)) % D);
+        const unsigned ui = (unsigned)i;
+        const int x = (int)(ui % (unsigned)W), y = (int)((ui / (unsigned)W) % (unsigned)H), z = (int)((ui / (unsigned)(W * H)) % (unsigned)D);
         out[i] = in_box(box, D, z, y, x) ? b[i] : a[i];
     }
 }
@@ -110,7 +111,8 @@ extern "C" int chap_box_mix(const chap_boxmix_params* p, void* stream) {
 __global__ void boxmask_kernel(const chap_boxmask_params P, int D) {
     const long total = (long)P.N * D * P.H * P.W;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % P.W), y = (int)((i / P.W) % P.H), z = (int)((i / ((long)P.W * P.H)) % D);
+        const unsigned ui = (unsigned)i;
+        const int x = (int)(ui % (unsigned)P.W), y = (int)((ui / (unsigned)P.W) % (unsigned)P.H), z = (int)((ui / (unsigned)(P.W * P.H)) % (unsigned)D);
         P.mask[i] = in_box(P.box, D, z, y, x) ? 0 : 1;
     }
 }

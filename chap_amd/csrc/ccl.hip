@@ -33,7 +33,8 @@ __global__ void lcc_merge_kernel(const int64_t* lab, int* L, int N, int D, int H
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int64_t c = lab[i];
         if (c <= 0) continue;
-        const int x = (int)(i % W), y = (int)((i / W) % H), z = (int)((i / ((long)W * H)) % D);
+        const unsigned ui = (unsigned)i;
+        const int x = (int)(ui % (unsigned)W), y = (int)((ui / (unsigned)W) % (unsigned)H), z = (int)((ui / (unsigned)(W * H)) % (unsigned)D);
         // "forward" half of the 8- (2D) / 26- (3D) neighbourhood: each undirected edge is visited once
         for (int dz = 0; dz <= (D > 1 ? 1 : 0); ++dz)
             for (int dy = (dz ? -1 : 0); dy <= 1; ++dy)

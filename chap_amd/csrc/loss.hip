@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void mix_loss_acc_kernel(const chap_mix_loss_p
         for (int i = 0; i < NA; ++i) a[k][i] = 0.f;
     const long P = P_.P, total = (long)P_.N * P;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long n = i / P, pp = i % P;
+        const long n = (unsigned)i / (unsigned)P, pp = (unsigned)i % (unsigned)P;
         float z[C], p[C], lse;
         softmax_px<C>(P_.logits, n * C * P + pp, P, z, p, lse);
         const float m = (float)P_.mask[i];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void mix_loss_bwd_kernel(const chap_mix_loss_p
     const long P = P_.P, total = (long)P_.N * P;
     const float w[2] = {P_.w_a, P_.w_b};
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long n = i / P, pp = i % P;
+        const long n = (unsigned)i / (unsigned)P, pp = (unsigned)i % (unsigned)P;
         float z[C], p[C], lse;
         softmax_px<C>(P_.logits, n * C * P + pp, P, z, p, lse);
         const float m = (float)P_.mask[i];
@@ -153,7 +153,7 @@ template <int C>
 __global__ __launch_bounds__(256) void pseudo_kernel(const chap_pseudo_params P_) {
     const long P = P_.P, total = (long)P_.N * P;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long n = i / P, pp = i % P, base = n * C * P + pp;
+        const long n = (unsigned)i / (unsigned)P, pp = (unsigned)i % (unsigned)P, base = n * C * P + pp;
         float z1[C], p1[C], l1, z2[C], p2[C], l2;
         softmax_px<C>(P_.logits1, base, P, z1, p1, l1);
         softmax_px<C>(P_.logits2, base, P, z2, p2, l2);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void kl_kernel(const chap_kl_params P_) {
     const float gs = P_.gscale * (P_.gscale_dev ? *P_.gscale_dev : 1.f) * inv;
     float acc = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long n = i / P, pp = i % P, base = n * C * P + pp;
+        const long n = (unsigned)i / (unsigned)P, pp = (unsigned)i % (unsigned)P, base = n * C * P + pp;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float z[C], p[C], lse;

@@ -4,6 +4,10 @@
 // the channel axis, wave64 shuffle reductions, one float atomic per block and channel.
 #include "common.h"
 
+// Index decoding uses 32-bit unsigned arithmetic (64-bit integer division costs ~100 VALU instructions on
+// gfx950 and turned these streaming kernels VALU-bound); entry points reject tensors with >= 2^32 elements.
+typedef unsigned int u32;
+
 // =========================================================================================
 // First conv, Cin = 1, k3 s1 "same" (unet.py:50 with in_chns=1; vnet.py:19 with n_channels=1).
 // One thread per output pixel computes all Cout (<= 32) channels; weights + bias live in LDS.
@@ -21,9 +25,10 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const chap_conv_c1_par
 #pragma unroll
     for (int c = 0; c < CO; ++c) { ssum[c] = 0.f; ssq[c] = 0.f; }
     for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
-        const int x = (int)(pix % P.W); long r = pix / P.W;
-        const int y = (int)(r % P.H); r /= P.H;
-        const int z = (int)(r % P.D); const int n = (int)(r / P.D);
+        const u32 up = (u32)pix;
+        const int x = (int)(up % (u32)P.W); u32 r = up / (u32)P.W;
+        const int y = (int)(r % (u32)P.H); r /= (u32)P.H;
+        const int z = (int)(r % (u32)P.D); const int n = (int)(r / (u32)P.D);
         float in[TAPS];
 #pragma unroll
         for (int dz = 0; dz < KD; ++dz)
@@ -91,9 +96,10 @@ __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const chap_conv_c1_bwd
     // ---- dx ----
     if (P.dx) {
         for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)nblocks * 256) {
-            const int x = (int)(pix % P.W); long r = pix / P.W;
-            const int y = (int)(r % P.H); r /= P.H;
-            const int z = (int)(r % P.D); const int n = (int)(r / P.D);
+            const u32 up = (u32)pix;
+            const int x = (int)(up % (u32)P.W); u32 r = up / (u32)P.W;
+            const int y = (int)(r % (u32)P.H); r /= (u32)P.H;
+            const int z = (int)(r % (u32)P.D); const int n = (int)(r / (u32)P.D);
             float a = 0.f;
 #pragma unroll
             for (int dz = 0; dz < KD; ++dz)
@@ -125,9 +131,10 @@ __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const chap_conv_c1_bwd
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) a[t] = 0.f;
         for (long pix = (long)blockIdx.x * PL + q; pix < npix; pix += (long)nblocks * PL) {
-            const int x = (int)(pix % P.W); long r = pix / P.W;
-            const int y = (int)(r % P.H); r /= P.H;
-            const int z = (int)(r % P.D); const int n = (int)(r / P.D);
+            const u32 up = (u32)pix;
+            const int x = (int)(up % (u32)P.W); u32 r = up / (u32)P.W;
+            const int y = (int)(r % (u32)P.H); r /= (u32)P.H;
+            const int z = (int)(r % (u32)P.D); const int n = (int)(r / (u32)P.D);
             const float gv = elem<T>::get(g[pix * CO + c]);
             ab += gv;
 #pragma unroll
@@ -256,9 +263,10 @@ __global__ __launch_bounds__(256) void act_pool2_kernel(const chap_pool_params P
     const int C8 = P.r.C / 8, OH = P.H / 2, OW = P.W / 2;
     const long total = (long)P.N * OH * OW * C8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c8 = (int)(i % C8) * 8; long r = i / C8;
-        const int ox = (int)(r % OW); r /= OW;
-        const int oy = (int)(r % OH); const int n = (int)(r / OH);
+        const u32 ui = (u32)i;
+        const int c8 = (int)(ui % (u32)C8) * 8; u32 r = ui / (u32)C8;
+        const int ox = (int)(r % (u32)OW); r /= (u32)OW;
+        const int oy = (int)(r % (u32)OH); const int n = (int)(r / (u32)OH);
         float best[8]; uint32_t bi[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -307,10 +315,11 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const chap_upsample_par
     const int OD = P.dims == 3 ? 2 * P.D : P.D, OH = 2 * P.H, OW = 2 * P.W;
     const long total = (long)P.N * OD * OH * OW * C8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c8 = (int)(i % C8) * 8; long r = i / C8;
-        const int ox = (int)(r % OW); r /= OW;
-        const int oy = (int)(r % OH); r /= OH;
-        const int oz = (int)(r % OD); const int n = (int)(r / OD);
+        const u32 ui = (u32)i;
+        const int c8 = (int)(ui % (u32)C8) * 8; u32 r = ui / (u32)C8;
+        const int ox = (int)(r % (u32)OW); r /= (u32)OW;
+        const int oy = (int)(r % (u32)OH); r /= (u32)OH;
+        const int oz = (int)(r % (u32)OD); const int n = (int)(r / (u32)OD);
         int x0, x1, y0, y1, z0, z1; float wx, wy, wz;
         ac_coord(ox, P.W, OW, x0, x1, wx);
         ac_coord(oy, P.H, OH, y0, y1, wy);
@@ -354,10 +363,11 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const chap_upsample
     const long total = (long)P.N * P.D * P.H * P.W * C8;
     const T* g = (const T*)P.g;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c8 = (int)(i % C8) * 8; long r = i / C8;
-        const int x = (int)(r % P.W); r /= P.W;
-        const int y = (int)(r % P.H); r /= P.H;
-        const int z = (int)(r % P.D); const int n = (int)(r / P.D);
+        const u32 ui = (u32)i;
+        const int c8 = (int)(ui % (u32)C8) * 8; u32 r = ui / (u32)C8;
+        const int x = (int)(r % (u32)P.W); r /= (u32)P.W;
+        const int y = (int)(r % (u32)P.H); r /= (u32)P.H;
+        const int z = (int)(r % (u32)P.D); const int n = (int)(r / (u32)P.D);
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -482,11 +492,16 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
             ld8(P.r.scale + c8, k0);
         }
     }
+    const bool need_coords = P.g_pool != nullptr || P.r.chan_mul != nullptr;
     if (prow < PPB) {
         for (long pix = (long)blockIdx.x * PPB + prow; pix < npix; pix += (long)gridDim.x * PPB) {
-            const int x = (int)(pix % P.W); long r = pix / P.W;
-            const int y = (int)(r % P.H); r /= P.H;
-            const int n = (int)(r / P.D);
+            int x = 0, y = 0, n = 0;
+            if (need_coords) {                     // wave-uniform: only the pooled gradient / Dropout3d path needs (n, y, x)
+                const u32 up = (u32)pix;
+                x = (int)(up % (u32)P.W); u32 r = up / (u32)P.W;
+                y = (int)(r % (u32)P.H); r /= (u32)P.H;
+                n = (int)(r / (u32)P.D);
+            }
             float raw[8], dz[8];
             act_bwd_dz<T>(P, sa, sb, n, pix, y, x, c8, raw, dz);
             if (!APPLY) {
@@ -504,9 +519,13 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
     if (!APPLY) {
         for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
         __syncthreads();
-        if (prow < PPB) {
+        // lanes l, l+C8, l+2*C8, ... of a wave hold the same 8 channels: shuffle-reduce them first so that
+        // only C8 lanes per wave touch LDS (256 threads x 16 same-address LDS atomics were ~10 us per block)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { atomicAdd(&red[c8 + j], s0[j]); atomicAdd(&red[C + c8 + j], s1[j]); }
+        for (int j = 0; j < 8; ++j) {
+            float a = s0[j], b = s1[j];
+            for (int o = C8; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            if ((threadIdx.x & 63) < C8) { atomicAdd(&red[c8 + j], a); atomicAdd(&red[C + c8 + j], b); }
         }
         __syncthreads();
         float* dst = P.sums + (long)(blockIdx.x % ACT_BWD_REPS) * 2 * C;
@@ -568,8 +587,9 @@ __global__ void planar_to_cl_kernel(const chap_planar_to_cl_params P) {
     const int Cp = P.Cpad > P.C ? P.Cpad : P.C;       // channels [C, Cpad) are written as zeros
     const long total = (long)P.N * P.P * Cp;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % Cp); long r = i / Cp;
-        const long pp = r % P.P; const int n = (int)(r / P.P);
+        const u32 ui = (u32)i;
+        const int c = (int)(ui % (u32)Cp); const u32 r = ui / (u32)Cp;
+        const long pp = r % (u32)P.P; const int n = (int)(r / (u32)P.P);
         const float v = c < P.C ? P.in[((long)n * P.C + c) * P.P + pp] : 0.f;
         ((T*)P.out)[(n * (long)P.P + pp) * P.out_ld + P.out_coff + c] = elem<T>::put(v);
     }
@@ -589,8 +609,9 @@ __global__ void cl_to_planar_kernel(const chap_cl_to_planar_params P) {
     const int C = P.r.C;
     const long total = (long)P.N * P.P * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long pp = i % P.P; long r = i / P.P;
-        const int c = (int)(r % C); const int n = (int)(r / C);
+        const u32 ui = (u32)i;
+        const long pp = ui % (u32)P.P; const u32 r = ui / (u32)P.P;
+        const int c = (int)(r % (u32)C); const int n = (int)(r / (u32)C);
         P.out[i] = src_load1<T>(P.r, n, (long)n * P.P + pp, c);
     }
 }
@@ -617,14 +638,18 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const chap_chansum_par
     for (int j = 0; j < 8; ++j) s[j] = 0.f;
     for (long pix = (long)blockIdx.x * PPB + prow; pix < P.npix; pix += (long)gridDim.x * PPB) {
         float v[8];
-        src_load8<T>(P.r, (int)(pix / P.pix_per_sample), pix, c8, v);
+        src_load8<T>(P.r, (int)((u32)pix / (u32)P.pix_per_sample), pix, c8, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] += v[j];
     }
     for (int i = threadIdx.x; i < C; i += 256) red[i] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&red[c8 + j], s[j]);
+    for (int j = 0; j < 8; ++j) {
+        float a = s[j];
+        for (int o = C8; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+        if ((threadIdx.x & 63) < C8) atomicAdd(&red[c8 + j], a);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&P.out[i], red[i]);
 }
