@@ -1,8 +1,10 @@
 // chap_conv_fwd / chap_pack_weights: argument checks, blocking choice, weight packing kernel.
 #include "common.h"
 
-int chap_conv_launch_bf16(const chap_conv_params* p, int KC, int NT, hipStream_t s);
-int chap_conv_launch_f32(const chap_conv_params* p, int KC, int NT, hipStream_t s);
+#define DECL_GEOM(dt, g) int chap_conv_launch_##dt##_g##g(const chap_conv_params* p, int KC, int NT, int MR, hipStream_t s);
+DECL_GEOM(bf16, 1) DECL_GEOM(bf16, 2) DECL_GEOM(bf16, 3) DECL_GEOM(bf16, 4) DECL_GEOM(bf16, 5)
+DECL_GEOM(f32, 1) DECL_GEOM(f32, 2) DECL_GEOM(f32, 3) DECL_GEOM(f32, 4) DECL_GEOM(f32, 5)
+typedef int (*conv_launch_fn)(const chap_conv_params*, int, int, int, hipStream_t);
 
 struct conv_blocking { int KC, GPT, NP, STEPS, nchunks, ntiles; };
 
@@ -43,11 +45,34 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     const int taps = p->ksize * p->ksize * (p->dims == 3 ? p->ksize : 1);
     conv_blocking b = blocking_for(Ck, taps, p->Cout);
     CHAP_CHECK_ARG(Ck % b.KC == 0, "chap_conv_fwd: K channels %d not a multiple of %d", Ck, b.KC);
-    const int NT = b.ntiles >= 4 ? 4 : (b.ntiles >= 2 ? 2 : 1);
-    if (p->dtype == CHAP_BF16) return chap_conv_launch_bf16(p, b.KC, NT, (hipStream_t)stream);
-    if (p->dtype == CHAP_F32) return chap_conv_launch_f32(p, b.KC, NT, (hipStream_t)stream);
-    chap_set_error("chap_conv_fwd: dtype=%d", p->dtype);
-    return CHAP_EINVAL;
+    // geometry family
+    const bool d3 = p->dims == 3;
+    int geom;
+    if (p->ksize == 3 && p->stride == 1) geom = d3 ? 2 : 1;
+    else if (p->ksize == 1 && p->stride == 1) geom = 3;
+    else if (p->ksize == 2 && p->stride == 2) geom = d3 ? 5 : 4;
+    else { chap_set_error("chap_conv_fwd: unsupported (ksize=%d, stride=%d)", p->ksize, p->stride); return CHAP_EUNSUPPORTED; }
+    if (p->combine == 1 && p->nsrc == 2 && geom != 2) { chap_set_error("chap_conv_fwd: add-combine is built for 3D k3 s1 only"); return CHAP_EUNSUPPORTED; }
+    // blocking: NT = 16-channel tiles per block, MR = 16-pixel rows per wave.  Large tiles (halo overhead,
+    // weight reuse) when the layer has plenty of pixels; small tiles when it would not fill 256 CUs.
+    int NT = b.ntiles >= 4 ? 4 : (b.ntiles >= 2 ? 2 : 1);
+    int MR = (geom == 2 || geom == 5) ? 1 : 2;
+    if (geom == 1 || geom == 3) {
+        const long px = (long)p->N * p->D * p->H * p->W;
+        auto blocks = [&](int mr, int nt) { return (long)p->N * p->D * cdiv(p->H, 4 * mr) * cdiv(p->W, 16) * cdiv(b.ntiles, nt); };
+        if (geom == 1 && b.KC == 16 && blocks(4, NT) >= 512) MR = 4;
+        else if (blocks(2, NT) >= 384) MR = 2;
+        else {
+            MR = 1;
+            while (NT > 1 && blocks(1, NT) < 384) NT >>= 1;
+        }
+        (void)px;
+    }
+    static const conv_launch_fn table[2][5] = {
+        {chap_conv_launch_f32_g1, chap_conv_launch_f32_g2, chap_conv_launch_f32_g3, chap_conv_launch_f32_g4, chap_conv_launch_f32_g5},
+        {chap_conv_launch_bf16_g1, chap_conv_launch_bf16_g2, chap_conv_launch_bf16_g3, chap_conv_launch_bf16_g4, chap_conv_launch_bf16_g5}};
+    if (p->dtype != CHAP_BF16 && p->dtype != CHAP_F32) { chap_set_error("chap_conv_fwd: dtype=%d", p->dtype); return CHAP_EINVAL; }
+    return table[p->dtype == CHAP_BF16][geom - 1](p, b.KC, NT, MR, (hipStream_t)stream);
 }
 
 // ---- weight packing ------------------------------------------------------------------------

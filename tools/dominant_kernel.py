@@ -1,0 +1,12 @@
+"""Launch ONLY the roofline kernel of bench.py (16->16 3x3 conv at 256x256, N=12, bf16, BN-affine
+prologue + statistics epilogue) a few times -- the target of the rocprofv3 --pmc passes that give
+`roofline.traffic` (FETCH_SIZE / WRITE_SIZE must be collected in separate passes on gfx950)."""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+import bench
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    r = bench.dominant_kernel_roofline(None, torch.bfloat16, n, 256)
+    print(r)
