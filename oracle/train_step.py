@@ -199,6 +199,7 @@ def iteration(sd, moms, volume_batch, label_batch, box_yx, iter_num, lr, args=No
         plab1 = largest_cc(arg1, nc) if a["nms"] else arg1
         plab2 = largest_cc(arg2, nc) if a["nms"] else arg2
         img_mask, loss_mask = (box_masks(lsub, *sp, *box_yx) if len(sp) == 2 else box_masks_3d(lsub, *sp, *box_yx))
+        img_mask, loss_mask = img_mask.to(volume_batch.device), loss_mask.to(volume_batch.device)
         net_input_unl = uimg_a * img_mask + img_a * (1 - img_mask)
         net_input_l = img_b * img_mask + uimg_b * (1 - img_mask)
         net_input_mix = torch.cat((net_input_l, net_input_unl))
@@ -221,10 +222,10 @@ def iteration(sd, moms, volume_batch, label_batch, box_yx, iter_num, lr, args=No
             key = "drop_V%d" % k if k < a["vat_iters"] else "drop_VF"
             return net(sd, xx, train=True, drop=inject.get(key), update_stats=False)
 
-        d0 = inject["d0"] if inject.get("d0") is not None else torch.rand(uimg_ab.shape) - 0.5
+        d0 = inject["d0"] if inject.get("d0") is not None else torch.rand(uimg_ab.shape, device=uimg_ab.device) - 0.5
         vat_loss, _ = vat2d(model_fn, uimg_ab, soft1, soft2, diff, d0, a["noise_mag"], a["epi"], a["vat_iters"], a["vat_sign"])
     else:
-        vat_loss = torch.zeros(())
+        vat_loss = torch.zeros((), device=volume_batch.device)
     loss = bcp_loss + cw * vat_loss
     names = [k for k, v in sd.items() if v.is_floating_point() and v.requires_grad]
     grads = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
