@@ -118,111 +118,141 @@ __device__ __forceinline__ void stage_halo(T* halo, const chap_src_t& s0, const 
 }
 
 // ---- register-staged prefetch of one halo (item = tile x K-chunk) ---------------------------------
+// Everything that does not depend on the tile is computed ONCE per thread (unit -> halo coordinates,
+// LDS offset, MFMA fragment offsets, output offsets); per item only a few adds/compares remain and all
+// global addresses are (wave-uniform 64-bit base) + (32-bit lane offset).
 template <typename T, int UNITS, bool ADD2> struct halo_regs {
     typename frag<T>::type raw[UNITS];
     typename frag<T>::type raw2[ADD2 ? UNITS : 1];
     uint2 keep[UNITS];
-    long gpix[UNITS];          // global pixel index, -1 = out of bounds (zero padding)
+    unsigned ok;               // bit j: unit j is inside the input (else zero padding)
 };
 
+template <int UNITS> struct unit_desc {
+    int hzyx[UNITS];           // hz << 20 | hy << 10 | hx   (-1: unit not used by this thread)
+    int rel[UNITS];            // (hz*IH + hy)*IW + hx : input pixel offset from the halo origin
+    int lds[UNITS];            // pix*PS + cgl*8 (elements)
+    int c8[UNITS];             // cgl*8
+};
+
+struct src_scalars {           // wave-uniform per-source values hoisted out of the loops
+    const void* ptr; const uint8_t* keep; const float* chan_mul;
+    int C, ld, coff; float slope_eff, keep_scale; bool has_keep, has_cm;
+};
+__device__ __forceinline__ src_scalars make_scalars(const chap_src_t& s) {
+    src_scalars r;
+    r.ptr = s.ptr; r.keep = s.keep; r.chan_mul = s.chan_mul; r.C = s.C; r.ld = s.ld; r.coff = s.coff;
+    r.slope_eff = s.act ? s.slope : 1.f; r.keep_scale = s.keep_scale; r.has_keep = s.keep != nullptr; r.has_cm = s.chan_mul != nullptr;
+    return r;
+}
+
 template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int UNITS>
-__device__ __forceinline__ void halo_issue(halo_regs<T, UNITS, ADD2>& R, const chap_conv_params& P, int n, int z0, int y0, int x0, int chunk) {
+__device__ __forceinline__ void halo_issue(halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, const src_scalars& s0, const src_scalars& s1,
+                                           int ID, int IH, int IW, int n, int z0, int y0, int x0, int chunk) {
     typedef conv_geom<KS, ST, D3, MR> G;
-    constexpr int GPT = KC / 8;
+    const int gz0 = z0 * G::STD - (D3 ? G::PAD : 0), gy0 = y0 * ST - G::PAD, gx0 = x0 * ST - G::PAD;
+    const long gp0 = (((long)n * ID + gz0) * IH + gy0) * IW + gx0;           // halo origin (may lie outside: only offsets that pass the bounds test are used)
+    const T* b0 = (const T*)s0.ptr + gp0 * s0.ld + s0.coff;
+    const T* b1 = (const T*)s1.ptr + gp0 * s1.ld + s1.coff;
+    const uint8_t* k0 = s0.keep + gp0 * s0.C;
+    const uint8_t* k1 = s1.keep + gp0 * s1.C;
+    const int cbase = chunk * KC;
+    R.ok = 0;
 #pragma unroll
     for (int j = 0; j < UNITS; ++j) {
-        const int u = threadIdx.x + 256 * j;
-        R.gpix[j] = -1;
-        if (u < G::HP * GPT) {
-            const int pix = u / GPT, cgl = u % GPT;
-            const int hx = pix % G::HW, hy = (pix / G::HW) % G::HH, hz = pix / (G::HW * G::HH);
-            const int gz = z0 * G::STD + hz - (D3 ? G::PAD : 0), gy = y0 * ST + hy - G::PAD, gx = x0 * ST + hx - G::PAD;
-            if (!(CHAP_ABLATE & 16) && (unsigned)gz < (unsigned)P.ID && (unsigned)gy < (unsigned)P.IH && (unsigned)gx < (unsigned)P.IW) {
-                const long gp = (((long)n * P.ID + gz) * P.IH + gy) * P.IW + gx;
-                R.gpix[j] = gp;
-                int c = chunk * KC + cgl * 8;
-                if (ADD2) {
-                    R.raw[j] = frag<T>::load((const T*)P.src[0].ptr + gp * P.src[0].ld + P.src[0].coff + c);
-                    R.raw2[j] = frag<T>::load((const T*)P.src[1].ptr + gp * P.src[1].ld + P.src[1].coff + c);
-                    if (P.src[0].keep) R.keep[j] = *(const uint2*)(P.src[0].keep + gp * P.src[0].C + c);
-                } else {
-                    const bool second = c >= P.src[0].C;
-                    const chap_src_t& s = second ? P.src[1] : P.src[0];
-                    if (second) c -= P.src[0].C;
-                    R.raw[j] = frag<T>::load((const T*)s.ptr + gp * s.ld + s.coff + c);
-                    if (s.keep) R.keep[j] = *(const uint2*)(s.keep + gp * s.C + c);
+        const int d = U.hzyx[j];
+        if (CHAP_ABLATE & 16) continue;
+        const int hz = d >> 20, hy = (d >> 10) & 1023, hx = d & 1023;
+        const bool ok = d >= 0 && (unsigned)(gz0 + hz) < (unsigned)ID && (unsigned)(gy0 + hy) < (unsigned)IH && (unsigned)(gx0 + hx) < (unsigned)IW;
+        if (ok) {
+            R.ok |= 1u << j;
+            int c = cbase + U.c8[j];
+            if (ADD2) {
+                R.raw[j] = frag<T>::load(b0 + U.rel[j] * s0.ld + c);
+                R.raw2[j] = frag<T>::load(b1 + U.rel[j] * s1.ld + c);
+                if (s0.has_keep) R.keep[j] = *(const uint2*)(k0 + U.rel[j] * s0.C + c);
+            } else {
+                const bool second = c >= s0.C;
+                c = second ? c - s0.C : c;
+                const T* b = second ? b1 : b0;
+                const int ld = second ? s1.ld : s0.ld;
+                R.raw[j] = frag<T>::load(b + U.rel[j] * ld + c);
+                const bool hk = second ? s1.has_keep : s0.has_keep;
+                if (hk) {
+                    const uint8_t* kb = second ? k1 : k0;
+                    const int kc = second ? s1.C : s0.C;
+                    R.keep[j] = *(const uint2*)(kb + U.rel[j] * kc + c);
                 }
             }
         }
     }
 }
 
-// affine cache layout in LDS: [src][2][Cmax]: scale then shift.
-template <typename T>
-__device__ __forceinline__ void lazy_transform(float v[8], const chap_src_t& s, const float* aff, int c, uint2 keep, int n) {
-    if (s.scale) {
+// affine cache layout in LDS: [src][scale | shift][CONV_MAX_AFFINE_C/2] (identity when a source has none)
+__device__ __forceinline__ void lazy_transform(float v[8], const float* aff, int c, float slope_eff, bool has_keep, uint2 keep, float keep_scale,
+                                               const float* cm) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fmaf(v[j], aff[c + j], aff[CONV_MAX_AFFINE_C / 2 + c + j]);
+    for (int j = 0; j < 8; ++j) {
+        const float z = fmaf(v[j], aff[c + j], aff[CONV_MAX_AFFINE_C / 2 + c + j]);
+        v[j] = z > 0.f ? z : z * slope_eff;
     }
-    if (s.act) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * s.slope;
-    }
-    if (s.keep) {
+    if (has_keep) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint32_t w = j < 4 ? keep.x : keep.y;
-            v[j] = ((w >> (8 * (j & 3))) & 0xff) ? v[j] * s.keep_scale : 0.f;
+            v[j] = ((w >> (8 * (j & 3))) & 0xff) ? v[j] * keep_scale : 0.f;
         }
     }
-    if (s.chan_mul) {
+    if (cm) {
         float a[8];
-        ld8(s.chan_mul + (long)n * s.C + c, a);
+        ld8(cm + c, a);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= a[j];
     }
 }
 
 template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int UNITS>
-__device__ __forceinline__ void halo_commit(const halo_regs<T, UNITS, ADD2>& R, T* halo, const chap_conv_params& P, const float* aff,
-                                            bool plain, int n, int chunk) {
-    typedef conv_geom<KS, ST, D3, MR> G;
-    constexpr int GPT = KC / 8, PS = pix_stride<T, KC>();
+__device__ __forceinline__ void halo_commit(const halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
+                                            const float* aff, bool plain, int n, int chunk) {
+    const int cbase = chunk * KC;
 #pragma unroll
     for (int j = 0; j < UNITS; ++j) {
-        const int u = threadIdx.x + 256 * j;
-        if (u < G::HP * GPT) {
-            const int pix = u / GPT, cgl = u % GPT;
-            T* dst = halo + pix * PS + cgl * 8;
-            if (R.gpix[j] < 0) { frag<T>::store(dst, frag<T>::zero()); continue; }
-            if (plain) { frag<T>::store(dst, R.raw[j]); continue; }
-            float v[8];
-            frag<T>::unpack(R.raw[j], v);
-            int c = chunk * KC + cgl * 8;
-            if (ADD2) {
-                lazy_transform<T>(v, P.src[0], aff, c, R.keep[j], n);
-                float w[8];
-                frag<T>::unpack(R.raw2[j], w);
-                lazy_transform<T>(w, P.src[1], aff + CONV_MAX_AFFINE_C, c, make_uint2(0, 0), n);
+        if (U.hzyx[j] < 0) continue;
+        T* dst = halo + U.lds[j];
+        if (!((R.ok >> j) & 1u)) { frag<T>::store(dst, frag<T>::zero()); continue; }
+        if (plain) { frag<T>::store(dst, R.raw[j]); continue; }
+        float v[8];
+        frag<T>::unpack(R.raw[j], v);
+        int c = cbase + U.c8[j];
+        if (ADD2) {
+            lazy_transform(v, aff, c, s0.slope_eff, s0.has_keep, R.keep[j], s0.keep_scale, s0.has_cm ? s0.chan_mul + (long)n * s0.C : nullptr);
+            float w[8];
+            frag<T>::unpack(R.raw2[j], w);
+            lazy_transform(w, aff + CONV_MAX_AFFINE_C, c, s1.slope_eff, false, make_uint2(0, 0), 1.f, s1.has_cm ? s1.chan_mul + (long)n * s1.C : nullptr);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] += w[k];
-            } else {
-                const bool second = c >= P.src[0].C;
-                if (second) lazy_transform<T>(v, P.src[1], aff + CONV_MAX_AFFINE_C, c - P.src[0].C, R.keep[j], n);
-                else lazy_transform<T>(v, P.src[0], aff, c, R.keep[j], n);
-            }
-            st8(dst, v);
+            for (int k = 0; k < 8; ++k) v[k] += w[k];
+        } else {
+            const bool second = c >= s0.C;
+            c = second ? c - s0.C : c;
+            const float* af = second ? aff + CONV_MAX_AFFINE_C : aff;
+            const float se = second ? s1.slope_eff : s0.slope_eff;
+            const bool hk = second ? s1.has_keep : s0.has_keep;
+            const float ks = second ? s1.keep_scale : s0.keep_scale;
+            const float* cm = second ? (s1.has_cm ? s1.chan_mul + (long)n * s1.C : nullptr) : (s0.has_cm ? s0.chan_mul + (long)n * s0.C : nullptr);
+            lazy_transform(v, af, c, se, hk, R.keep[j], ks, cm);
         }
+        st8(dst, v);
     }
 }
 
 // tile index -> (n, z0, y0, x0)
 template <int TH, int TW>
 __device__ __forceinline__ void tile_coords(long tile, int tiles_x, int tiles_y, int D, int& n, int& z0, int& y0, int& x0) {
-    const int tx = (int)(tile % tiles_x); tile /= tiles_x;
-    const int ty = (int)(tile % tiles_y); tile /= tiles_y;
-    z0 = (int)(tile % D); n = (int)(tile / D);
-    x0 = tx * TW; y0 = ty * TH;
+    const unsigned t = (unsigned)tile;
+    const unsigned tx = t % (unsigned)tiles_x; unsigned r = t / (unsigned)tiles_x;
+    const unsigned ty = r % (unsigned)tiles_y; r /= (unsigned)tiles_y;
+    z0 = (int)(r % (unsigned)D); n = (int)(r / (unsigned)D);
+    x0 = (int)tx * TW; y0 = (int)ty * TH;
 }
 
 template <typename T, int KS, int ST, bool D3, int KC, int NT, int MR, bool ADD2, bool WLDS>
@@ -250,6 +280,8 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const chap_conv_params P)
     const bool plain = (CHAP_ABLATE & 4) ||
                        (!ADD2 && P.src[0].scale == nullptr && !P.src[0].act && P.src[0].keep == nullptr && P.src[0].chan_mul == nullptr &&
                         (P.nsrc < 2 || (P.src[1].scale == nullptr && !P.src[1].act && P.src[1].keep == nullptr && P.src[1].chan_mul == nullptr)));
+    const src_scalars s0 = make_scalars(P.src[0]);
+    const src_scalars s1 = make_scalars(P.nsrc > 1 ? P.src[1] : P.src[0]);
 
     // XCD-aware tile walk: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous range
     // of tiles so that the halos re-read by neighbouring tiles are L2 hits.
@@ -261,7 +293,31 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const chap_conv_params P)
     const long my_tiles = (t_begin + bix < t_end) ? (t_end - t_begin - bix + bpx - 1) / bpx : 0;
     const long nitems = my_tiles * nchunks;
 
-    // ---- one-time per block: affine cache (only when a source carries one), resident weights ----
+    // ---- one-time per thread: unit descriptors, MFMA fragment offsets ----
+    unit_desc<UNITS> U;
+#pragma unroll
+    for (int j = 0; j < UNITS; ++j) {
+        const int u = threadIdx.x + 256 * j;
+        U.hzyx[j] = -1; U.rel[j] = 0; U.lds[j] = 0; U.c8[j] = 0;
+        if (u < G::HP * GPT) {
+            const int pix = u / GPT, cgl = u % GPT;
+            const int hx = pix % G::HW, hy = (pix / G::HW) % G::HH, hz = pix / (G::HW * G::HH);
+            U.hzyx[j] = (hz << 20) | (hy << 10) | hx;
+            U.rel[j] = (hz * P.IH + hy) * P.IW + hx;
+            U.lds[j] = pix * PS + cgl * 8;
+            U.c8[j] = cgl * 8;
+        }
+    }
+    int xoff[STEPS];                                            // LDS element offset of this lane's B fragment (row m = 0), -1 = zero fragment
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        const int p = step * 4 + g;
+        const int tap = p / GPT, cgl = p % GPT;
+        const int dx = tap % KS, dy = (tap / KS) % KS, dz = tap / (KS * KS);
+        xoff[step] = p < NP ? ((dz * G::HH + (wave * MR) * ST + dy) * G::HW + px * ST + dx) * PS + cgl * 8 : -1;
+    }
+
+    // ---- one-time per block: affine cache, resident weights ----
     if (!plain) {
         for (int s = 0; s < P.nsrc; ++s) {
             const bool has = P.src[s].scale != nullptr;
@@ -284,23 +340,48 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const chap_conv_params P)
     }
 
     f32x4 acc[MR][NT];
-    float ssum[NT][4], ssq[NT][4];
+    float ssum[NT][4], ssq[NT][4], bj[NT][4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
+        const int nl = (nt0 + t) * 16 + 4 * g;
+        const int cb = P.out_mode == 1 ? (nl % P.out_Cn) : nl;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { ssum[t][j] = 0.f; ssq[t][j] = 0.f; }
+        for (int j = 0; j < 4; ++j) {
+            ssum[t][j] = 0.f; ssq[t][j] = 0.f;
+            bj[t][j] = (P.bias && nl + j < P.Cout) ? P.bias[cb + j] : 0.f;
+        }
+    }
     const bool do_stats = P.stats != nullptr;
     const int SD2 = (P.dims == 3) ? 2 : 1;
+    // per-lane output offsets relative to the tile origin (elements), one per (t): row term added per m
+    int ooff[NT], orow;                                         // orow = element stride of one tile row
+    {
+        const int OW = P.out_mode == 1 ? 2 * P.W : P.W, OH = P.out_mode == 1 ? 2 * P.H : P.H;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int nl = (nt0 + t) * 16 + 4 * g;
+            if (P.out_planar) {
+                ooff[t] = px;                                   // + channel plane handled at store time
+            } else if (P.out_mode == 1) {
+                const int sub = nl / P.out_Cn, oc = nl % P.out_Cn;
+                const int sx = sub & 1, sy = (sub >> 1) & 1, sz = (sub >> 2) & 1;
+                ooff[t] = (((sz * OH) + sy) * OW + 2 * px + sx) * P.out_ld + P.out_coff + oc;
+            } else {
+                ooff[t] = px * P.out_ld + P.out_coff + nl;
+            }
+        }
+        orow = P.out_planar ? P.W : (P.out_mode == 1 ? 2 * OW * P.out_ld : P.W * P.out_ld);
+    }
 
     halo_regs<T, UNITS, ADD2> R;
     int n = 0, z0 = 0, y0 = 0, x0 = 0;
     int nn = 0, nz0 = 0, ny0 = 0, nx0 = 0;                      // coordinates of the item being prefetched
     if (nitems > 0) {
         tile_coords<G::TH, G::TW>(t_begin + bix, tiles_x, tiles_y, P.D, nn, nz0, ny0, nx0);
-        halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, P, nn, nz0, ny0, nx0, 0);
+        halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, nz0, ny0, nx0, 0);
     }
     __syncthreads();                                            // affine cache (+ resident weights) visible
-    if (nitems > 0) halo_commit<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, halo0, P, aff, plain, nn, 0);
+    if (nitems > 0) halo_commit<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, halo0, s0, s1, aff, plain, nn, 0);
     __syncthreads();
 
     long tile_k = 0;                                            // index into this block's tile list
@@ -323,12 +404,12 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const chap_conv_params P)
                 nchunk = 0;
                 tile_coords<G::TH, G::TW>(t_begin + bix + (tile_k + 1) * bpx, tiles_x, tiles_y, P.D, nn, nz0, ny0, nx0);
             }
-            halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, P, nn, nz0, ny0, nx0, nchunk);
+            halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, nz0, ny0, nx0, nchunk);
         }
         // ---- MFMA over the taps of this chunk
         const T* wc_g = (const T*)P.wpacked + (long)chunk * STEPS * wstep + ((long)nt0 * 64 + lane) * 8;
         const T* wc_l = wlds + ((long)chunk * STEPS * NT * 64 + lane) * 8;
-#pragma unroll 3
+#pragma unroll
         for (int step = 0; step < ((CHAP_ABLATE & 2) ? 0 : STEPS); ++step) {
             F wf[NT];
 #pragma unroll
@@ -336,15 +417,10 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const chap_conv_params P)
                 if (WLDS) wf[t] = frag<T>::load(wc_l + ((long)step * NT + t) * 512);
                 else wf[t] = (nt0 + t < ntiles_total) ? frag<T>::load(wc_g + (long)step * wstep + t * 512) : frag<T>::zero();
             }
-            const int p = step * 4 + g;
-            const int tap = p / GPT, cgl = p % GPT;
-            const int dx = tap % KS, dy = (tap / KS) % KS, dz = tap / (KS * KS);
-            const bool pv = p < NP;
+            const int xo = xoff[step];
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                const int row = wave * MR + m;
-                const int off = ((dz * G::HH + row * ST + dy) * G::HW + px * ST + dx) * PS + cgl * 8;
-                F xf = pv ? frag<T>::load(cur + off) : frag<T>::zero();
+                F xf = xo >= 0 ? frag<T>::load(cur + xo + m * (ST * G::HW * PS)) : frag<T>::zero();
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     if (CHAP_ABLATE & 1) { float kx[8], kw[8]; frag<T>::unpack(xf, kx); frag<T>::unpack(wf[t], kw); asm volatile("" :: "v"(kx[0]), "v"(kx[7]), "v"(kw[0]), "v"(kw[7])); } else mma8(acc[m][t], wf[t], xf);
@@ -353,47 +429,35 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const chap_conv_params P)
         }
         // ---- epilogue after the last K-chunk of a tile: lane holds D[cout = 16*t + 4*g + j][pixel (row m, x = px)]
         if (chunk == nchunks - 1) {
-            const int gx = x0 + px;
+            const bool xok = x0 + px < P.W;
+            // wave-uniform 64-bit origin of this tile in the output, 32-bit lane offsets on top
+            long o0;
+            if (P.out_planar) o0 = ((long)n * P.Cout * P.D + z0) * P.H * P.W + (long)y0 * P.W + x0;     // + c*plane
+            else if (P.out_mode == 1) o0 = ((((long)n * (P.D * SD2) + z0 * SD2) * (2 * P.H) + 2 * y0) * (2 * P.W) + 2 * x0) * P.out_ld;
+            else o0 = ((((long)n * P.D + z0) * P.H + y0) * P.W + x0) * P.out_ld;
+            const long plane = (long)P.D * P.H * P.W;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int nl = (nt0 + t) * 16 + 4 * g;            // logical output channel of j = 0
                 if (nl >= P.Cout) continue;
-                float bj[4] = {0.f, 0.f, 0.f, 0.f};
-                const int cb = P.out_mode == 1 ? (nl % P.out_Cn) : nl;
-                if (P.bias) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (nl + j < P.Cout) bj[j] = P.bias[cb + j];
-                }
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
-                    const int gy = y0 + wave * MR + m;
-                    const bool valid = gy < P.H && gx < P.W;
+                    const int row = wave * MR + m;
+                    const bool valid = xok && (y0 + row < P.H);
                     float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = acc[m][t][j] + bj[j];
-                        if (valid) { ssum[t][j] += v[j]; ssq[t][j] += v[j] * v[j]; }
-                    }
+                    for (int j = 0; j < 4; ++j) v[j] = acc[m][t][j] + bj[t][j];
                     if (!valid) continue;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { ssum[t][j] += v[j]; ssq[t][j] += v[j] * v[j]; }
                     if (CHAP_ABLATE & 8) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
                     if (P.out_planar) {
-                        float* o = (float*)P.out;
-                        const long plane = (long)P.D * P.H * P.W;
-                        const long pp = ((long)z0 * P.H + gy) * P.W + gx;
+                        float* o = (float*)P.out + o0 + row * orow + ooff[t];
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            if (nl + j < P.Cout) o[((long)n * P.Cout + nl + j) * plane + pp] = v[j];
+                            if (nl + j < P.Cout) o[(nl + j) * plane] = v[j];
                     } else {
-                        long opix; int oc;
-                        if (P.out_mode == 1) {
-                            const int sub = nl / P.out_Cn; oc = nl % P.out_Cn;
-                            const int sx = sub & 1, sy = (sub >> 1) & 1, sz = (sub >> 2) & 1;
-                            opix = (((long)n * (P.D * SD2) + z0 * SD2 + sz) * (2 * P.H) + 2 * gy + sy) * (2 * P.W) + 2 * gx + sx;
-                        } else {
-                            oc = nl;
-                            opix = (((long)n * P.D + z0) * P.H + gy) * P.W + gx;
-                        }
-                        const long oi = opix * P.out_ld + P.out_coff + oc;
+                        const long oi = o0 + row * orow + ooff[t];
                         if (nl + 3 < P.Cout) {
                             if (P.out_f32) st4((float*)P.out + oi, v); else st4((T*)P.out + oi, v);
                         } else {
@@ -408,7 +472,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const chap_conv_params P)
             ++tile_k;
         }
         // ---- land the prefetched halo in the other buffer; one barrier per item
-        if (has_next) halo_commit<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, nxt, P, aff, plain, nn, nchunk);
+        if (has_next) halo_commit<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, nxt, s0, s1, aff, plain, nn, nchunk);
         chunk = nchunk == nchunks ? 0 : nchunk;
         __syncthreads();
     }
