@@ -16,6 +16,9 @@
 #pragma once
 #include "common.h"
 
+#ifndef CHAP_CONV_MINWAVES
+#define CHAP_CONV_MINWAVES 1      // __launch_bounds__ 2nd argument (waves per SIMD) -- lab knob
+#endif
 #ifndef CHAP_ABLATE
 #define CHAP_ABLATE 0          // tools/lab/conv_lab.hip builds ablated variants; the library never does
 #endif
@@ -256,7 +259,7 @@ __device__ __forceinline__ void tile_coords(long tile, int tiles_x, int tiles_y,
 }
 
 template <typename T, int KS, int ST, bool D3, int KC, int NT, int MR, bool ADD2, bool WLDS>
-__global__ __launch_bounds__(256) void conv_fwd_kernel(const chap_conv_params P) {
+__global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES : (KC == 16 && !D3 ? 4 : 1))) void conv_fwd_kernel(const chap_conv_params P) {
     typedef conv_geom<KS, ST, D3, MR> G;
     typedef typename frag<T>::type F;
     constexpr int GPT = KC / 8, PS = pix_stride<T, KC>();
@@ -329,13 +332,26 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(const chap_conv_params P)
     }
     const long wstep = (long)ntiles_total * 64 * 8;             // packed elements per (chunk, step)
     if (WLDS) {
-        // resident copy: [chunk][step][t < NT][64 lanes][8]
+        // resident copy: [chunk][step][t < NT][64 lanes][8]; 8 loads in flight per thread (a load->store->load
+        // chain would serialise ~1 us of L2 latency per 16 bytes)
         const long tot = (long)nchunks * STEPS * NT * 64;
-        for (long i = threadIdx.x; i < tot; i += 256) {
-            const int ln = (int)(i & 63); long r = i >> 6;
-            const int t = (int)(r % NT); r /= NT;                // r = chunk*STEPS + step
-            F f = (nt0 + t < ntiles_total) ? frag<T>::load((const T*)P.wpacked + r * wstep + ((long)(nt0 + t) * 64 + ln) * 8) : frag<T>::zero();
-            frag<T>::store(wlds + i * 8, f);
+        for (long i0 = threadIdx.x; i0 < tot; i0 += 256 * 8) {
+            F f[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const long i = i0 + 256 * k;
+                f[k] = frag<T>::zero();
+                if (i < tot) {
+                    const int ln = (int)(i & 63); long r = i >> 6;
+                    const int t = (int)(r % NT); r /= NT;            // r = chunk*STEPS + step
+                    if (nt0 + t < ntiles_total) f[k] = frag<T>::load((const T*)P.wpacked + r * wstep + ((long)(nt0 + t) * 64 + ln) * 8);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const long i = i0 + 256 * k;
+                if (i < tot) frag<T>::store(wlds + i * 8, f[k]);
+            }
         }
     }
 

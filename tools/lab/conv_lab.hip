@@ -45,7 +45,7 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         double us = ms * 1e3 / 20, gb = (double)(nin + nout) * 2 / us / 1e3;
-        printf("abl=%2d %-28s occ=%d grid=%5ldx%d lds=%6zu : %8.1f us %7.1f GB/s\n", CHAP_ABLATE, name, occ, gx, gy, lds, us, gb);
+        printf("mw=%d abl=%2d %-28s occ=%d grid=%5ldx%d lds=%6zu : %8.1f us %7.1f GB/s\n", CHAP_CONV_MINWAVES, CHAP_ABLATE, name, occ, gx, gy, lds, us, gb);
     }
     hipFree(x); hipFree(y); hipFree(wp); hipFree(sc); hipFree(sh); hipFree(st);
 }
