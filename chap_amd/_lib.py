@@ -75,12 +75,12 @@ class ActBwdParams(C.Structure):
 
 
 class PoolParams(C.Structure):
-    _fields_ = [("r", Src), ("out", _vp), ("idx", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("dtype", _i32)]
+    _fields_ = [("r", Src), ("out", _vp), ("idx", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("dtype", _i32), ("D", _i32)]
 
 
 class UpsampleParams(C.Structure):
     _fields_ = [("r", Src), ("out", _vp), ("out_ld", _i32), ("out_coff", _i32),
-                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("dims", _i32), ("dtype", _i32)]
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("dims", _i32), ("dtype", _i32), ("half_pixel", _i32)]
 
 
 class UpsampleBwdParams(C.Structure):

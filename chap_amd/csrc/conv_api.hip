@@ -11,7 +11,7 @@ struct conv_blocking { int KC, GPT, NP, STEPS, nchunks, ntiles; };
 // K-side geometry shared by the packer and the kernel: Ck = GEMM-K channels, taps = kernel taps.
 static conv_blocking blocking_for(int Ck, int taps, int Cout_logical) {
     conv_blocking b;
-    b.KC = Ck >= 32 ? 32 : 16;
+    b.KC = (Ck >= 32 && Ck % 32 == 0) ? 32 : 16;      // e.g. 16 + 32 concatenated channels (unet_3D) walk in chunks of 16
     b.GPT = b.KC / 8;
     b.NP = taps * b.GPT;
     b.STEPS = (b.NP + 3) / 4;

@@ -260,24 +260,25 @@ extern "C" int chap_bn_eval_affine(const chap_bn_eval_params* p, void* stream) {
 // 2x2 max-pool of a lazy activation. One thread per (pooled pixel, 8 channels).
 template <typename T>
 __global__ __launch_bounds__(256) void act_pool2_kernel(const chap_pool_params P) {
-    const int C8 = P.r.C / 8, OH = P.H / 2, OW = P.W / 2;
-    const long total = (long)P.N * OH * OW * C8;
+    const int D = P.D > 1 ? P.D : 1, KZ = P.D > 1 ? 2 : 1;
+    const int C8 = P.r.C / 8, OD = D / KZ, OH = P.H / 2, OW = P.W / 2;
+    const long total = (long)P.N * OD * OH * OW * C8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const u32 ui = (u32)i;
         const int c8 = (int)(ui % (u32)C8) * 8; u32 r = ui / (u32)C8;
         const int ox = (int)(r % (u32)OW); r /= (u32)OW;
-        const int oy = (int)(r % (u32)OH); const int n = (int)(r / (u32)OH);
+        const int oy = (int)(r % (u32)OH); r /= (u32)OH;
+        const int oz = (int)(r % (u32)OD); const int n = (int)(r / (u32)OD);
         float best[8]; uint32_t bi[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long pix = ((long)n * P.H + 2 * oy + (k >> 1)) * P.W + 2 * ox + (k & 1);
+        for (int k = 0; k < 4 * KZ; ++k) {
+            const long pix = (((long)n * D + KZ * oz + (k >> 2)) * P.H + 2 * oy + ((k >> 1) & 1)) * P.W + 2 * ox + (k & 1);
             float v[8];
             src_load8<T>(P.r, n, pix, c8, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j)
                 if (k == 0 || v[j] > best[j] || v[j] != v[j]) { best[j] = v[j]; bi[j] = k; }
         }
-        const long op = ((long)n * OH + oy) * OW + ox;
+        const long op = (((long)n * OD + oz) * OH + oy) * OW + ox;
         st8((T*)P.out + op * P.r.C + c8, best);
         if (P.idx) {
             uint2 m;
@@ -289,8 +290,8 @@ __global__ __launch_bounds__(256) void act_pool2_kernel(const chap_pool_params P
 }
 extern "C" int chap_act_pool2(const chap_pool_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->r.ptr && p->out, "chap_act_pool2: null argument");
-    CHAP_CHECK_ARG(p->r.C % 8 == 0 && p->H % 2 == 0 && p->W % 2 == 0, "chap_act_pool2: C%%8, even H/W required");
-    const long total = (long)p->N * (p->H / 2) * (p->W / 2) * (p->r.C / 8);
+    CHAP_CHECK_ARG(p->r.C % 8 == 0 && p->H % 2 == 0 && p->W % 2 == 0 && (p->D <= 1 || p->D % 2 == 0), "chap_act_pool2: C%%8, even dims required");
+    const long total = (long)p->N * (p->D > 1 ? p->D / 2 : 1) * (p->H / 2) * (p->W / 2) * (p->r.C / 8);
     const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(act_pool2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(act_pool2_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
@@ -300,9 +301,10 @@ extern "C" int chap_act_pool2(const chap_pool_params* p, void* stream) {
 
 // =========================================================================================
 // 2x upsample, align_corners=True: src = dst * (in-1)/(out-1)  (F.interpolate bilinear/trilinear).
-__device__ __forceinline__ void ac_coord(int o, int in, int out, int& i0, int& i1, float& w1) {
-    const float sc = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
-    const float f = sc * (float)o;
+__device__ __forceinline__ void ac_coord(int o, int in, int out, int& i0, int& i1, float& w1, bool half_pixel = false) {
+    const float sc = half_pixel ? (float)in / (float)out : (out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f);
+    float f = half_pixel ? sc * ((float)o + 0.5f) - 0.5f : sc * (float)o;     // area_pixel_compute_source_index
+    if (f < 0.f) f = 0.f;
     i0 = (int)f;
     if (i0 > in - 1) i0 = in - 1;
     i1 = i0 + 1 < in ? i0 + 1 : in - 1;
@@ -321,9 +323,10 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const chap_upsample_par
         const int oy = (int)(r % (u32)OH); r /= (u32)OH;
         const int oz = (int)(r % (u32)OD); const int n = (int)(r / (u32)OD);
         int x0, x1, y0, y1, z0, z1; float wx, wy, wz;
-        ac_coord(ox, P.W, OW, x0, x1, wx);
-        ac_coord(oy, P.H, OH, y0, y1, wy);
-        if (P.dims == 3) ac_coord(oz, P.D, OD, z0, z1, wz); else { z0 = z1 = oz; wz = 0.f; }
+        const bool hp = P.half_pixel != 0;
+        ac_coord(ox, P.W, OW, x0, x1, wx, hp);
+        ac_coord(oy, P.H, OH, y0, y1, wy, hp);
+        if (P.dims == 3) ac_coord(oz, P.D, OD, z0, z1, wz, hp); else { z0 = z1 = oz; wz = 0.f; }
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;

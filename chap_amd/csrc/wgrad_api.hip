@@ -11,7 +11,7 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     q->Ca = p->combine == 0 ? p->a[0].C + (p->na > 1 ? p->a[1].C : 0) : p->a[0].C;
     q->Cb = p->b.C;
     CHAP_CHECK_ARG(q->Ca % 16 == 0 && q->Cb % 8 == 0, "chap_wgrad: Ca=%d must be a multiple of 16, Cb=%d of 8", q->Ca, q->Cb);
-    q->KC = q->Ca >= 32 ? 32 : 16;
+    q->KC = (q->Ca >= 32 && q->Ca % 32 == 0) ? 32 : 16;
     CHAP_CHECK_ARG(q->Ca % q->KC == 0, "chap_wgrad: Ca=%d not a multiple of %d", q->Ca, q->KC);
     q->taps = p->ksize * p->ksize * (p->dims == 3 ? p->ksize : 1);
     const bool small_tile = (p->ksize == 2 && p->dims == 3);

@@ -37,6 +37,8 @@ class Op:
         self.slope = kw.get("slope", 0.0)  # activation after BN (when bn is set)
         self.head = kw.get("head", False)  # planar fp32 logits
         self.drop = kw.get("drop")         # (site, p, 'elem' | 'chan') applied to the OUTPUT value
+        self.inorm = kw.get("inorm", False)          # InstanceNorm (no affine) + ReLU after the conv: batch-of-one statistics
+        self.half_pixel = kw.get("half_pixel", False)  # 'up': align_corners=False
 
 
 class Program:
@@ -73,6 +75,8 @@ class Executor:
         self.m, self.prog = module, program
         self._packed = {}          # (key, kind, dtype) -> packed weights
         self._packed_version = None
+        self._ident = {}           # C -> (ones, zeros) for InstanceNorm (no affine)
+        self.has_inorm = any(op.inorm for op in program.ops)
 
     # ---------------------------------------------------------------- parameters
     def _sd(self):
@@ -103,12 +107,14 @@ class Executor:
         N = x.shape[0]
         sp = tuple(x.shape[2:])
         D, H, W = ((1,) + sp) if dims == 2 else sp
+        if self.has_inorm and (save or N != 1):
+            raise NotImplementedError("chap_amd: InstanceNorm networks (unet_3D) are inference-only and run one sample per pass")
         S = Saved()
         S.train, S.x = train, x
         vals, vdims = S.vals, S.dims
         vdims[prog.in_name] = (D, H, W)
         # one zeroed fp32 arena for all BN statistics / affines of this pass
-        nbn = sum(op.cout for op in prog.ops if op.bn)
+        nbn = sum(op.cout for op in prog.ops if op.bn or op.inorm)
         arena = torch.zeros(nbn * (2 * STATS_REPS + 4), dtype=torch.float32, device=dev)
         apos = 0
 
@@ -124,10 +130,11 @@ class Executor:
             if k == "pool":
                 src = vals[op.srcs[0]]
                 d, h, w = vdims[op.srcs[0]]
-                out = torch.empty(N, 1, h // 2, w // 2, src.C, dtype=dtype, device=dev)
-                idx = torch.empty(N, 1, h // 2, w // 2, src.C, dtype=torch.uint8, device=dev) if save else None
-                ops.act_pool2(src, out, idx)
-                vals[op.out], vdims[op.out] = Lazy(out), (1, h // 2, w // 2)
+                od = d // 2 if dims == 3 else 1
+                out = torch.empty(N, od, h // 2, w // 2, src.C, dtype=dtype, device=dev)
+                idx = torch.empty(N, od, h // 2, w // 2, src.C, dtype=torch.uint8, device=dev) if save else None
+                ops.act_pool2(src, out, idx, dims=dims)
+                vals[op.out], vdims[op.out] = Lazy(out), (od, h // 2, w // 2)
                 if save:
                     S.pool_idx[op.out] = idx
                 continue
@@ -136,11 +143,11 @@ class Executor:
                 d, h, w = vdims[op.srcs[0]]
                 od = 2 * d if dims == 3 else d
                 out = torch.empty(N, od, 2 * h, 2 * w, src.C, dtype=dtype, device=dev)
-                ops.upsample2x(src, out, dims=dims)
+                ops.upsample2x(src, out, dims=dims, half_pixel=op.half_pixel)
                 vals[op.out], vdims[op.out] = Lazy(out), (od, 2 * h, 2 * w)
                 continue
             # ---- convolutions
-            stats = take(STATS_REPS * 2 * op.cout) if (op.bn and train) else None
+            stats = take(STATS_REPS * 2 * op.cout) if ((op.bn and train) or op.inorm) else None
             bias = sd[op.b] if op.b else None
             if k == "c1":
                 gd = (D, H, W)
@@ -175,7 +182,14 @@ class Executor:
                     ops.conv_fwd(srcs, wp, bias, op.cout, out, grid=(N,) + gd, in_dims=ind, ksize=ks, stride=st, dims=dims,
                                  combine=op.combine, stats=stats, stats_reps=STATS_REPS)
             vdims[op.out] = gd
-            if op.bn:
+            if op.inorm:            # InstanceNorm3d (affine=False) + ReLU: statistics of this single sample
+                scale, shift = take(op.cout), take(op.cout)
+                if op.cout not in self._ident:
+                    self._ident[op.cout] = (torch.ones(op.cout, device=dev), torch.zeros(op.cout, device=dev))
+                one, zero = self._ident[op.cout]
+                ops.bn_finalize(stats, STATS_REPS, one, zero, None, None, None, gd[0] * gd[1] * gd[2], BN_EPS, 0.0, scale, shift)
+                lz = Lazy(out, scale, shift, True, 0.0)
+            elif op.bn:
                 scale, shift = take(op.cout), take(op.cout)
                 if train:
                     mean, invstd = take(op.cout), take(op.cout)

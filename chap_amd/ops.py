@@ -146,17 +146,19 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps, scale, shift):
     L.call("chap_bn_eval_affine", p, _stream())
 
 
-def act_pool2(lazy, out, idx=None):
+def act_pool2(lazy, out, idx=None, dims=2):
     p = L.PoolParams()
     lazy.fill(p.r)
     p.out, p.idx = out.data_ptr(), _p(idx)
     p.N, p.H, p.W = lazy.raw.shape[0], lazy.raw.shape[2], lazy.raw.shape[3]
+    p.D = lazy.raw.shape[1] if dims == 3 else 1
     p.dtype = dt(lazy.raw)
     L.call("chap_act_pool2", p, _stream())
 
 
-def upsample2x(lazy, out, *, dims, out_coff=0):
+def upsample2x(lazy, out, *, dims, out_coff=0, half_pixel=False):
     p = L.UpsampleParams()
+    p.half_pixel = int(half_pixel)
     lazy.fill(p.r)
     p.out, p.out_ld, p.out_coff = out.data_ptr(), out.shape[-1], out_coff
     p.N, p.D, p.H, p.W = lazy.raw.shape[:4]

@@ -203,7 +203,7 @@ int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream);
 int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream);
 
 /* nn.MaxPool2d(2) of a lazy activation (unet.py:69): out [N][H/2][W/2][C] + arg-max idx. */
-typedef struct { chap_src_t r; void* out; uint8_t* idx; int32_t N, H, W, dtype; } chap_pool_params;
+typedef struct { chap_src_t r; void* out; uint8_t* idx; int32_t N, H, W, dtype; int32_t D; /* D > 1: MaxPool3d(2) (utils.py / unet_3D.py:33) */ } chap_pool_params;
 int chap_act_pool2(const chap_pool_params* p, void* stream);
 
 /* nn.Upsample(scale_factor=2, bilinear/trilinear, align_corners=True) of a (lazy) tensor
@@ -211,6 +211,7 @@ int chap_act_pool2(const chap_pool_params* p, void* stream);
 typedef struct {
     chap_src_t r;  void* out; int32_t out_ld, out_coff;
     int32_t N, D, H, W;  /* INPUT dims */  int32_t dims, dtype;
+    int32_t half_pixel;  /* 1: align_corners=False (nn.Upsample default, networks/utils.py:264) */
 } chap_upsample_params;
 int chap_upsample2x(const chap_upsample_params* p, void* stream);
 typedef struct {

@@ -80,3 +80,34 @@ def test_vnet_eval_and_random_dropout(golden_dir):
         a, b = t(x, update_stats=False)
         (a.sum() + b.sum()).backward()
     assert torch.isfinite(x.grad).all() and x.grad.abs().sum() > 0
+
+
+def test_unet3d_inference(golden_dir):
+    """unet_3D (InstanceNorm3d, MaxPool3d, trilinear align_corners=False) against the reference's logits,
+    and the sliding-window recipe of test_3D_util.test_single_case on a padded volume."""
+    from chap_amd.networks import unet_3D
+    g = _load(golden_dir, "unet3d_32.npz")
+    u = net_factory_3d("unet_3D", 1, 2, "test", DEV)
+    u.load_state_dict(oinit.unet_3d_state(int(g["state_seed"])), strict=True)
+    u.eval()
+    x = torch.from_numpy(g["x"]).to(DEV)
+    o = u(x)
+    assert relerr(o, g["eval_logits0"]) < 1e-4
+    o2 = u(torch.cat([x, x.flip(2)]))                  # batch of 2 = two batch-of-one passes (InstanceNorm)
+    assert relerr(o2[:1], g["eval_logits0"]) < 1e-4
+    with pytest.raises(NotImplementedError):
+        u.train()(x)
+
+
+def test_pool3d_and_half_pixel_upsample():
+    import torch.nn.functional as F
+    from chap_amd import ops
+    from tests.test_kernels_gpu import cl, uncl
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 4, 6, 8, generator=g)
+    out = torch.empty(1, 2, 3, 4, 16, device=DEV)
+    ops.act_pool2(ops.Lazy(cl(x, torch.float32)), out, None, dims=3)
+    assert relerr(uncl(out), F.max_pool3d(x, 2)) < 1e-6
+    up = torch.empty(1, 8, 12, 16, 16, device=DEV)
+    ops.upsample2x(ops.Lazy(cl(x, torch.float32)), up, dims=3, half_pixel=True)
+    assert relerr(uncl(up), F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=False)) < 1e-5
