@@ -100,8 +100,9 @@ class Executor:
         return t
 
     # ---------------------------------------------------------------- forward
-    def forward(self, x, *, train, dtype, save, update_stats=True, drop_masks=None, rng=None):
-        """x: fp32 [N, 1, *spatial] contiguous. Returns (list of planar fp32 logits, Saved|None)."""
+    def forward(self, x, *, train, dtype, save, update_stats=True, drop_masks=None, rng=None, want=()):
+        """x: fp32 [N, 1, *spatial] contiguous. Returns (list of planar fp32 logits, Saved|None, extras):
+        extras = the activated values named in `want`, materialised as planar fp32 [N, C, *spatial]."""
         prog, sd, dims = self.prog, self._sd(), self.prog.dims
         dev = x.device
         N = x.shape[0]
@@ -226,7 +227,13 @@ class Executor:
                         lz.chan_mul = cm
             vals[op.out] = lz
         logits = [outs[h] for h in prog.heads]
-        return logits, (S if save else None)
+        extras = []
+        for name in want:
+            lz, (d_, h_, w_) = vals[name], vdims[name]
+            o = torch.empty((N, lz.C) + ((h_, w_) if dims == 2 else (d_, h_, w_)), dtype=torch.float32, device=dev)
+            ops.cl_to_planar(lz, o)
+            extras.append(o)
+        return logits, (S if save else None), extras
 
     # ---------------------------------------------------------------- backward
     def backward(self, S, dlogits, *, dtype, need_wgrad, need_dx):

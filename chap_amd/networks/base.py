@@ -16,10 +16,12 @@ class _NetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, opts, x, *params):
-        logits, S = net._exec.forward(x, train=opts["train"], dtype=net.compute_dtype, save=opts["save"],
-                                      update_stats=opts["update_stats"], drop_masks=opts["drop_masks"], rng=net._rng)
-        ctx.net, ctx.S = net, S
-        return tuple(logits)
+        logits, S, extras = net._exec.forward(x, train=opts["train"], dtype=net.compute_dtype, save=opts["save"],
+                                              update_stats=opts["update_stats"], drop_masks=opts["drop_masks"], rng=net._rng,
+                                              want=opts.get("want", ()))
+        ctx.net, ctx.S, ctx.nlogits = net, S, len(logits)
+        ctx.mark_non_differentiable(*extras)
+        return tuple(logits) + tuple(extras)
 
     @staticmethod
     def backward(ctx, *dlogits):
@@ -28,7 +30,7 @@ class _NetFn(torch.autograd.Function):
             raise RuntimeError("chap_amd: backward through a forward pass that saved nothing")
         need_dx = ctx.needs_input_grad[2]
         need_w = any(ctx.needs_input_grad[3:])
-        dl = [None if g is None else g.contiguous() for g in dlogits]
+        dl = [None if g is None else g.contiguous() for g in dlogits[:ctx.nlogits]]
         dx = net._exec.backward(ctx.S, dl, dtype=net.compute_dtype, need_wgrad=need_w, need_dx=need_dx)
         ctx.S = None
         return (None, None, dx) + (None,) * (len(ctx.needs_input_grad) - 3)
@@ -158,7 +160,7 @@ class ChapNet(nn.Module):
         return r
 
     # ------------------------------------------------------------------ running the program
-    def _run(self, x, *, drop_masks=None, update_stats=True):
+    def _run(self, x, *, drop_masks=None, update_stats=True, want=()):
         if x.dim() != self.dims + 2 or x.shape[1] != 1:
             raise ValueError("chap_amd: expected input [N, 1, %s], got %s" % (", ".join("*" * self.dims), tuple(x.shape)))
         self._ensure_flat()
@@ -169,7 +171,7 @@ class ChapNet(nn.Module):
         if self._frozen or not grad_on:
             params = [p.detach() for p in params]
         save = grad_on and (x.requires_grad or any(p.requires_grad for p in params))
-        opts = dict(train=self.training, save=save, update_stats=update_stats, drop_masks=drop_masks)
+        opts = dict(train=self.training, save=save, update_stats=update_stats, drop_masks=drop_masks, want=tuple(want))
         return _NetFn.apply(self, opts, x, *params)
 
 

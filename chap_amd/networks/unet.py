@@ -106,9 +106,10 @@ class DualDecoder(ChapNet):
                 drop_masks=None, update_stats=True):
         if dropout:
             raise NotImplementedError("chap_amd: channel-dropout branch (perform_dropout) is a next-row item, see DESIGN.md")
+        if with_feat:       # unet.py:289-290: also the five encoder features (materialised NCHW fp32, detached)
+            out = self._run(x, drop_masks=drop_masks, update_stats=update_stats, want=["e0", "e1", "e2", "e3", "e4"])
+            return out[0], out[1], list(out[2:])
         out = self._run(x, drop_masks=drop_masks, update_stats=update_stats)
-        if with_feat:
-            raise NotImplementedError("chap_amd: with_feat=True is not built yet")
         return out[0], out[1]
 
 

@@ -151,3 +151,17 @@ def test_cpu_module_fails_loudly():
     m = DualDecoder(1, 4, {"decoder_type": "mcnet"})
     with pytest.raises(Exception, match="no CPU fallback"):
         m(torch.rand(1, 1, 32, 32))
+
+
+def test_with_feat_returns_encoder_features(golden_dir):
+    g = _load(golden_dir, "dualdecoder2d_64.npz")
+    state = oinit.dual_decoder_2d_state(int(g["state_seed"]))
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).eval()
+    m.load_state_dict(state, strict=True)
+    x = torch.from_numpy(g["x"])
+    with torch.no_grad():
+        o1, o2, feats = m(x.to(DEV), with_feat=True)
+        r1, r2, rf = onets.dual_decoder_2d(state, x, train=False, with_feat=True)
+    assert relerr(o1, r1) < 1e-4 and len(feats) == 5
+    for a, b in zip(feats, rf):
+        assert a.shape == b.shape and relerr(a, b) < 1e-4
