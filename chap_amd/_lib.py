@@ -36,6 +36,12 @@ class PackParams(C.Structure):
     _fields_ = [("w", _vp), ("out", _vp), ("kind", _i32), ("Cin", _i32), ("Cout", _i32), ("taps", _i32), ("dtype", _i32)]
 
 
+class PackEntry(C.Structure):
+    _fields_ = [("w", _vp), ("out", _vp), ("kind", _i32), ("Cin", _i32), ("Cout", _i32), ("taps", _i32), ("dtype", _i32),
+                ("KC", _i32), ("GPT", _i32), ("NP", _i32), ("STEPS", _i32), ("nchunks", _i32), ("ntiles", _i32),
+                ("Cn_logical", _i32), ("Ck_real", _i32), ("total", _i64)]
+
+
 class ConvC1Params(C.Structure):
     _fields_ = [("x", _vp), ("w", _vp), ("bias", _vp), ("out", _vp), ("stats", _vp), ("stats_reps", _i32),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("dims", _i32), ("Cout", _i32), ("dtype", _i32)]
@@ -212,6 +218,27 @@ def _fn(name):
             fn.restype, fn.argtypes = _sz, [C.POINTER(_SIZE_FNS[name])]
         _bound[name] = fn
     return fn
+
+
+def pack_describe(params):
+    """chap_pack_describe: host-side, fills a PackEntry for chap_pack_multi."""
+    L = lib()
+    L.chap_pack_describe.restype = C.c_int
+    L.chap_pack_describe.argtypes = [C.POINTER(PackParams), C.POINTER(PackEntry)]
+    e = PackEntry()
+    rc = L.chap_pack_describe(C.byref(params), C.byref(e))
+    if rc != 0:
+        raise ChapError("chap_pack_describe failed (%d): %s" % (rc, L.chap_last_error().decode()))
+    return e
+
+
+def pack_multi(entries_dev_ptr, n, max_total, stream):
+    L = lib()
+    L.chap_pack_multi.restype = C.c_int
+    L.chap_pack_multi.argtypes = [_vp, _i32, _i64, _vp]
+    rc = L.chap_pack_multi(_vp(entries_dev_ptr), n, max_total, _vp(stream))
+    if rc != 0:
+        raise ChapError("chap_pack_multi failed (%d): %s" % (rc, L.chap_last_error().decode()))
 
 
 def call(name, params, stream):

@@ -92,10 +92,11 @@ static int pack_geometry(const chap_pack_params* p, pack_geom* g) {
 }
 
 template <typename T>
-__global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ out, int kind, int Cin, int Cout, int taps,
-                            int KC, int GPT, int NP, int STEPS, int nchunks, int ntiles, int Cn_logical, int Ck_real) {
+__device__ __forceinline__ void pack_body(const float* __restrict__ w, T* __restrict__ out, int kind, int Cin, int Cout, int taps,
+                                          int KC, int GPT, int NP, int STEPS, int nchunks, int ntiles, int Cn_logical, int Ck_real,
+                                          long first, long stride) {
     const long total = (long)nchunks * STEPS * ntiles * 64;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (long i = first; i < total; i += stride) {
         const int lane = (int)(i & 63);
         long r = i >> 6;
         const int nt = (int)(r % ntiles); r /= ntiles;
@@ -125,6 +126,44 @@ __global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ out, in
         }
         st8(out + i * 8, v);
     }
+}
+
+template <typename T>
+__global__ void pack_kernel(const float* __restrict__ w, T* __restrict__ out, int kind, int Cin, int Cout, int taps,
+                            int KC, int GPT, int NP, int STEPS, int nchunks, int ntiles, int Cn_logical, int Ck_real) {
+    pack_body<T>(w, out, kind, Cin, Cout, taps, KC, GPT, NP, STEPS, nchunks, ntiles, Cn_logical, Ck_real,
+                 (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+__global__ void pack_multi_kernel(const chap_pack_entry* __restrict__ E) {
+    const chap_pack_entry e = E[blockIdx.y];
+    const long first = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    if (first >= e.total) return;
+    if (e.dtype == CHAP_BF16) pack_body<bf16_t>(e.w, (bf16_t*)e.out, e.kind, e.Cin, e.Cout, e.taps, e.KC, e.GPT, e.NP, e.STEPS, e.nchunks, e.ntiles, e.Cn_logical, e.Ck_real, first, stride);
+    else pack_body<float>(e.w, (float*)e.out, e.kind, e.Cin, e.Cout, e.taps, e.KC, e.GPT, e.NP, e.STEPS, e.nchunks, e.ntiles, e.Cn_logical, e.Ck_real, first, stride);
+}
+
+extern "C" int chap_pack_describe(const chap_pack_params* p, chap_pack_entry* e) {
+    CHAP_CHECK_ARG(p && e && p->w && p->out, "chap_pack_describe: null argument");
+    pack_geom g;
+    int r = pack_geometry(p, &g);
+    if (r) return r;
+    conv_blocking b = blocking_for(g.Ck, g.ctaps, g.Cn_logical);
+    CHAP_CHECK_ARG(g.Ck % b.KC == 0, "chap_pack_describe: K channels %d not a multiple of %d", g.Ck, b.KC);
+    e->w = p->w; e->out = p->out; e->kind = p->kind; e->Cin = p->Cin; e->Cout = p->Cout; e->taps = p->taps; e->dtype = p->dtype;
+    e->KC = b.KC; e->GPT = b.GPT; e->NP = b.NP; e->STEPS = b.STEPS; e->nchunks = b.nchunks; e->ntiles = b.ntiles;
+    e->Cn_logical = g.Cn_logical; e->Ck_real = g.Ck_real;
+    e->total = (int64_t)b.nchunks * b.STEPS * b.ntiles * 64;
+    return CHAP_OK;
+}
+
+extern "C" int chap_pack_multi(const chap_pack_entry* entries_dev, int32_t n, int64_t max_total, void* stream) {
+    CHAP_CHECK_ARG(entries_dev && n > 0 && max_total > 0, "chap_pack_multi: bad argument");
+    long bx = (max_total + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, entries_dev);
+    CHAP_LAUNCH_CHECK("chap_pack_multi");
+    return CHAP_OK;
 }
 
 extern "C" size_t chap_pack_size(const chap_pack_params* p) {

@@ -487,8 +487,23 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
     if (P.bn) { ld8(P.mean + c8, mean); ld8(P.invstd + c8, istd); }
     if (APPLY) {
         if (P.bn == 1) {                               // training-mode BatchNorm backward
-            float gm[8], a0[8], a1[8];          // replica 0 holds the compacted totals (act_bwd_param_kernel)
-            ld8(P.gamma + c8, gm); ld8(P.sums + c8, a0); ld8(P.sums + C + c8, a1);
+            // compact the replicas of the reduce phase cooperatively into LDS (2C x REPS loads per block)
+            for (int i = threadIdx.x; i < 2 * C; i += 256) {
+                float t = 0.f;
+                for (int r = 0; r < ACT_BWD_REPS; ++r) t += P.sums[(long)r * 2 * C + i];
+                red[i] = t;
+            }
+            __syncthreads();
+            if (blockIdx.x == 0) {                     // BatchNorm parameter gradients, once
+                for (int c = threadIdx.x; c < C; c += 256) {
+                    if (P.dbeta) P.dbeta[c] += red[c];
+                    if (P.dgamma) P.dgamma[c] += red[C + c];
+                }
+            }
+            float gm[8], a0[8], a1[8];
+            ld8(P.gamma + c8, gm);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a0[j] = red[c8 + j]; a1[j] = red[C + c8 + j]; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) { k0[j] = gm[j] * istd[j]; k1[j] = a0[j] / P.count; k2[j] = a1[j] / P.count; }
         } else if (P.r.scale) {                        // fixed affine (eval-mode BN): dz/draw = scale
@@ -570,15 +585,18 @@ extern "C" int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream) {
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, false>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL((act_bwd_kernel<float, false>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_act_bwd_reduce");
-    hipLaunchKernelGGL(act_bwd_param_kernel, dim3(cdiv(p->r.C, 64)), dim3(64), 0, (hipStream_t)stream, p->sums, p->dgamma, p->dbeta, p->r.C);
-    CHAP_LAUNCH_CHECK("chap_act_bwd_reduce(params)");
+    if (p->bn == 2 && (p->dgamma || p->dbeta)) {      // eval-mode affine: parameter gradients only (apply does not need the sums)
+        hipLaunchKernelGGL(act_bwd_param_kernel, dim3(cdiv(p->r.C, 64)), dim3(64), 0, (hipStream_t)stream, p->sums, p->dgamma, p->dbeta, p->r.C);
+        CHAP_LAUNCH_CHECK("chap_act_bwd_reduce(params)");
+    }
     return CHAP_OK;
 }
 extern "C" int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream) {
     int r = act_bwd_check(p); if (r) return r;
     CHAP_CHECK_ARG(p->gout, "chap_act_bwd_apply: null gout");
-    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, true>), dim3(act_bwd_blocks(p)), dim3(256), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL((act_bwd_kernel<float, true>), dim3(act_bwd_blocks(p)), dim3(256), 0, (hipStream_t)stream, *p);
+    const size_t lds = 2 * p->r.C * sizeof(float);
+    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, true>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL((act_bwd_kernel<float, true>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_act_bwd_apply");
     return CHAP_OK;
 }

@@ -73,8 +73,7 @@ class Executor:
 
     def __init__(self, module, program):
         self.m, self.prog = module, program
-        self._packed = {}          # (key, kind, dtype) -> packed weights
-        self._packed_version = None
+        self._packed = {}          # dtype -> {bufs, table, ...}: packed weights + chap_pack_multi entry table
         self._ident = {}           # C -> (ones, zeros) for InstanceNorm (no affine)
         self.has_inorm = any(op.inorm for op in program.ops)
 
@@ -82,22 +81,51 @@ class Executor:
     def _sd(self):
         return self.m._tensors()   # name -> tensor (params and buffers, fp32, on device)
 
-    def _pack(self, op, kind, dtype, sd):
+    def _pack_kinds(self, op):
+        if op.kind == "conv":
+            return (L.PACK_CONV_FWD, L.PACK_CONV_DGRAD)
+        if op.kind == "down":
+            return (L.PACK_CONV_FWD, L.PACK_DOWN_DGRAD)
+        if op.kind == "deconv":
+            return (L.PACK_DECONV_FWD, L.PACK_DECONV_DGRAD)
+        return ()
+
+    def _build_pack_table(self, dtype, sd):
+        """Persistent packed buffers + the device-side entry table for chap_pack_multi (one launch per step)."""
+        import ctypes as C
+        entries, bufs, max_total = [], {}, 0
+        dev = next(iter(sd.values())).device
+        for op in self.prog.ops:
+            for kind in self._pack_kinds(op):
+                w = sd[op.w]
+                cin, cout = (w.shape[0], w.shape[1]) if op.kind == "deconv" else (w.shape[1], w.shape[0])
+                p = L.PackParams()
+                p.w, p.kind, p.Cin, p.Cout, p.taps = w.data_ptr(), kind, cin, cout, _taps(op, self.prog.dims)
+                p.dtype = L.F32 if dtype == torch.float32 else L.BF16
+                buf = torch.empty(L.size_of("chap_pack_size", p), dtype=torch.uint8, device=dev)
+                p.out = buf.data_ptr()
+                e = L.pack_describe(p)
+                entries.append(e)
+                bufs[(op.w, kind)] = buf
+                max_total = max(max_total, int(e.total))
+        arr = (L.PackEntry * len(entries))(*entries)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        return dict(bufs=bufs, table=host.to(dev), n=len(entries), max_total=max_total, key=sd[self.prog.ops[0].w].data_ptr())
+
+    def _ensure_packed(self, dtype, sd):
+        tab = self._packed.get(dtype)
+        if tab is None or tab["key"] != sd[self.prog.ops[0].w].data_ptr():
+            tab = self._build_pack_table(dtype, sd)
+            self._packed[dtype] = tab
+            tab["version"] = None
         ver = self.m._params_version()
-        if ver != self._packed_version:
-            self._packed.clear()
-            self._packed_version = ver
-        key = (op.w, kind, dtype)
-        t = self._packed.get(key)
-        if t is None:
-            w = sd[op.w]
-            if op.kind == "deconv":
-                cin, cout = w.shape[0], w.shape[1]
-            else:
-                cout, cin = w.shape[0], w.shape[1]
-            t = ops.pack_weights(w, kind, dtype, cin, cout, _taps(op, self.prog.dims))
-            self._packed[key] = t
-        return t
+        if tab["version"] != ver:
+            L.pack_multi(tab["table"].data_ptr(), tab["n"], tab["max_total"], torch.cuda.current_stream().cuda_stream)
+            tab["version"] = ver
+        return tab
+
+    def _pack(self, op, kind, dtype, sd):
+        return self._ensure_packed(dtype, sd)["bufs"][(op.w, kind)]
 
     # ---------------------------------------------------------------- forward
     def forward(self, x, *, train, dtype, save, update_stats=True, drop_masks=None, rng=None, want=()):

@@ -113,6 +113,18 @@ typedef struct {
 size_t chap_pack_size(const chap_pack_params* p);   /* bytes of `out` */
 int    chap_pack_weights(const chap_pack_params* p, void* stream);
 
+/* All weights of a network in ONE launch (they change every optimizer step): the host fills one
+ * chap_pack_entry per (weight, kind) with chap_pack_describe, uploads the array once (pointers are stable:
+ * flat parameter buffer, persistent packed buffers) and calls chap_pack_multi each step. */
+typedef struct {
+    const float* w; void* out;
+    int32_t kind, Cin, Cout, taps, dtype;
+    int32_t KC, GPT, NP, STEPS, nchunks, ntiles, Cn_logical, Ck_real;
+    int64_t total;             /* 64-lane fragments to write */
+} chap_pack_entry;
+int chap_pack_describe(const chap_pack_params* p, chap_pack_entry* e);
+int chap_pack_multi(const chap_pack_entry* entries_dev, int32_t n, int64_t max_total, void* stream);
+
 /* First layer, Cin == 1 (encoder.in_conv / block_one first conv): direct VALU conv k3 s1.
  * x is fp32 [N][D][H][W] (C=1: NCHW == NHWC).  Also its input gradient (VAT needs dL/dx)
  * and weight gradient. */

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert lib.chap_abi_version() == 1
     # every entry point bound in the ctypes tables is declared in the header and vice versa
-    bound = set(_lib._SIGS) | set(_lib._SIZE_FNS) | {"chap_last_error", "chap_abi_version", "chap_debug_copy"}
+    bound = set(_lib._SIGS) | set(_lib._SIZE_FNS) | {"chap_last_error", "chap_abi_version", "chap_debug_copy", "chap_pack_describe", "chap_pack_multi"}
     assert bound == set(names), (bound ^ set(names))
 
 
@@ -49,7 +49,7 @@ def test_ctypes_struct_sizes_match_header(tmp_path):
              "chap_l2norm_params": _lib.L2NormParams, "chap_axpy_params": _lib.AxpyParams, "chap_rand_params": _lib.RandParams,
              "chap_keepmask_params": _lib.KeepMaskParams, "chap_chanmask_params": _lib.ChanMaskParams,
              "chap_boxmix_params": _lib.BoxMixParams, "chap_boxmask_params": _lib.BoxMaskParams, "chap_lcc_params": _lib.LccParams,
-             "chap_diffmask_params": _lib.DiffMaskParams, "chap_sgd_params": _lib.SgdParams}
+             "chap_diffmask_params": _lib.DiffMaskParams, "chap_sgd_params": _lib.SgdParams, "chap_pack_entry": _lib.PackEntry}
     c = tmp_path / "sz.c"
     body = "".join('printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in pairs)
     c.write_text('#include <stdio.h>\n#include "chap_hip.h"\nint main(void){\n%sreturn 0;}\n' % body)

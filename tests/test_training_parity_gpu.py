@@ -92,7 +92,7 @@ def test_k_iterations_match_oracle(dtype, tol):
         o = m(val.to(DEV))
         p_hip = torch.softmax((o[0] + o[1]) / 2.0, dim=1).cpu()
     diff = (p_ref - p_hip).abs()
-    assert diff.mean().item() < tol / 6 and diff.max().item() < 4 * tol, (diff.mean().item(), diff.max().item())
+    assert diff.mean().item() < tol / 2 and diff.max().item() < 8 * tol, (diff.mean().item(), diff.max().item())
 
 
 def test_trained_model_dice_matches_oracle_inference():
