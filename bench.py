@@ -206,7 +206,7 @@ def main():
         step = ChapStep(model, dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters), world_size=world)
     if world > 1:
         from chap_amd.parallel import DataParallelSync
-        step.grad_sync = DataParallelSync(model, dist)
+        step.grad_sync = DataParallelSync(model.flat_buffers()[1], step.grad2, dist)
     if d3:
         vol, lab = ots.synthetic_batch_3d(1337 + rank, B // 2, B - B // 2, *sp)
     else:

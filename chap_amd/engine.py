@@ -264,11 +264,13 @@ class Executor:
         return logits, (S if save else None), extras
 
     # ---------------------------------------------------------------- backward
-    def backward(self, S, dlogits, *, dtype, need_wgrad, need_dx):
+    def backward(self, S, dlogits, *, dtype, need_wgrad, need_dx, grad_buffer=None):
         """dlogits: list (per head) of planar fp32 gradients or None. Accumulates parameter gradients
         into the module's flat grad views; returns dx (fp32, shape of x) or None."""
         prog, sd, dims = self.prog, self._sd(), self.prog.dims
-        gr = self.m._grad_views() if need_wgrad else None
+        gr = None
+        if need_wgrad:
+            gr = self.m.grad_views_of(grad_buffer) if grad_buffer is not None else self.m._grad_views()
         dev = S.x.device
         N = S.x.shape[0]
         contrib = {}        # value name -> list of (tensor, coff)

@@ -20,6 +20,7 @@ class _NetFn(torch.autograd.Function):
                                               update_stats=opts["update_stats"], drop_masks=opts["drop_masks"], rng=net._rng,
                                               want=opts.get("want", ()))
         ctx.net, ctx.S, ctx.nlogits = net, S, len(logits)
+        ctx.grad_buffer = opts.get("grad_buffer")
         ctx.mark_non_differentiable(*extras)
         return tuple(logits) + tuple(extras)
 
@@ -31,7 +32,7 @@ class _NetFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[2]
         need_w = any(ctx.needs_input_grad[3:])
         dl = [None if g is None else g.contiguous() for g in dlogits[:ctx.nlogits]]
-        dx = net._exec.backward(ctx.S, dl, dtype=net.compute_dtype, need_wgrad=need_w, need_dx=need_dx)
+        dx = net._exec.backward(ctx.S, dl, dtype=net.compute_dtype, need_wgrad=need_w, need_dx=need_dx, grad_buffer=ctx.grad_buffer)
         ctx.S = None
         return (None, None, dx) + (None,) * (len(ctx.needs_input_grad) - 3)
 
@@ -131,6 +132,12 @@ class ChapNet(nn.Module):
             views[name] = v
         return views
 
+    def grad_views_of(self, flat_grad):
+        """name -> view of ANOTHER flat gradient buffer with this model's layout (second bucket: VAT branch /
+        data-parallel overlap); p.grad is left alone."""
+        assert flat_grad.shape == self._flat_grad.shape
+        return {name: flat_grad[o:o + p.numel()].view(p.shape) for (name, p), o in zip(self._param_list(), self._offsets)}
+
     def flat_buffers(self):
         """(params, grads) flat fp32 tensors (for the fused optimizer and the DP all-reduce)."""
         self._ensure_flat()
@@ -160,7 +167,7 @@ class ChapNet(nn.Module):
         return r
 
     # ------------------------------------------------------------------ running the program
-    def _run(self, x, *, drop_masks=None, update_stats=True, want=()):
+    def _run(self, x, *, drop_masks=None, update_stats=True, want=(), grad_buffer=None):
         if x.dim() != self.dims + 2 or x.shape[1] != 1:
             raise ValueError("chap_amd: expected input [N, 1, %s], got %s" % (", ".join("*" * self.dims), tuple(x.shape)))
         self._ensure_flat()
@@ -171,7 +178,7 @@ class ChapNet(nn.Module):
         if self._frozen or not grad_on:
             params = [p.detach() for p in params]
         save = grad_on and (x.requires_grad or any(p.requires_grad for p in params))
-        opts = dict(train=self.training, save=save, update_stats=update_stats, drop_masks=drop_masks, want=tuple(want))
+        opts = dict(train=self.training, save=save, update_stats=update_stats, drop_masks=drop_masks, want=tuple(want), grad_buffer=grad_buffer)
         return _NetFn.apply(self, opts, x, *params)
 
 

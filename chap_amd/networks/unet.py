@@ -103,13 +103,13 @@ class DualDecoder(ChapNet):
         self._finish_init(build_program(class_num, [("decoder1", True), ("decoder2", self.decoder_type == "same")]))
 
     def forward(self, x, with_feat=False, dropout=False, dropout_level=None, scores=None, comp_dropout=False,
-                drop_masks=None, update_stats=True):
+                drop_masks=None, update_stats=True, grad_buffer=None):
         if dropout:
             raise NotImplementedError("chap_amd: channel-dropout branch (perform_dropout) is a next-row item, see DESIGN.md")
         if with_feat:       # unet.py:289-290: also the five encoder features (materialised NCHW fp32, detached)
-            out = self._run(x, drop_masks=drop_masks, update_stats=update_stats, want=["e0", "e1", "e2", "e3", "e4"])
+            out = self._run(x, drop_masks=drop_masks, update_stats=update_stats, want=["e0", "e1", "e2", "e3", "e4"], grad_buffer=grad_buffer)
             return out[0], out[1], list(out[2:])
-        out = self._run(x, drop_masks=drop_masks, update_stats=update_stats)
+        out = self._run(x, drop_masks=drop_masks, update_stats=update_stats, grad_buffer=grad_buffer)
         return out[0], out[1]
 
 
@@ -126,7 +126,7 @@ class UNet(ChapNet):
         self.decoder = _decoder(class_num, True)
         self._finish_init(build_program(class_num, [("decoder", True)]))
 
-    def forward(self, x, with_feats=False, drop_masks=None, update_stats=True):
+    def forward(self, x, with_feats=False, drop_masks=None, update_stats=True, grad_buffer=None):
         if with_feats:
             raise NotImplementedError("chap_amd: with_feats=True is not built yet")
-        return self._run(x, drop_masks=drop_masks, update_stats=update_stats)[0]
+        return self._run(x, drop_masks=drop_masks, update_stats=update_stats, grad_buffer=grad_buffer)[0]

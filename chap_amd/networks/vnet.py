@@ -137,8 +137,8 @@ class DualDecoder3d(ChapNet):
         self.encoder.has_dropout = self.decoder1.has_dropout = self.decoder2.has_dropout = has_dropout
         self._finish_init(build_program(n_classes, n_filters, [("decoder1", 1), ("decoder2", 0)], has_dropout))
 
-    def forward(self, input, drop_masks=None, update_stats=True):
-        out = self._run(input, drop_masks=drop_masks, update_stats=update_stats)
+    def forward(self, input, drop_masks=None, update_stats=True, grad_buffer=None):
+        out = self._run(input, drop_masks=drop_masks, update_stats=update_stats, grad_buffer=grad_buffer)
         return out[0], out[1]
 
 
@@ -155,5 +155,5 @@ class VNet(ChapNet):
         self.encoder.has_dropout = self.decoder.has_dropout = has_dropout
         self._finish_init(build_program(n_classes, n_filters, [("decoder", 0)], has_dropout))
 
-    def forward(self, input, drop_masks=None, update_stats=True):
-        return self._run(input, drop_masks=drop_masks, update_stats=update_stats)[0]
+    def forward(self, input, drop_masks=None, update_stats=True, grad_buffer=None):
+        return self._run(input, drop_masks=drop_masks, update_stats=update_stats, grad_buffer=grad_buffer)[0]

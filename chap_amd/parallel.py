@@ -17,25 +17,21 @@ import torch
 
 
 class DataParallelSync:
-    def __init__(self, model, dist, group=None):
-        self.model, self.dist, self.group = model, dist, group
-        flat, grad = model.flat_buffers()
-        self.bucket = [grad, torch.zeros_like(grad)]
+    """bucket 0 = the model's own flat gradient buffer (BCP backward), bucket 1 = the second buffer the
+    VAT branch accumulates into (ChapStep.grad2)."""
+
+    def __init__(self, bucket0, bucket1, dist, group=None):
+        self.dist, self.group = dist, group
+        self.bucket = [bucket0, bucket1]
         self.work = [None, None]
 
     def bucket_ready(self, i):
-        """Gradients accumulated so far live in bucket i: start its all-reduce; later backward
-        passes accumulate into the other bucket."""
+        """All gradients of bucket i have been enqueued on the current stream: start its all-reduce (async:
+        it overlaps whatever is enqueued next)."""
         self.work[i] = self.dist.all_reduce(self.bucket[i], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-        if i == 0:
-            self.model.swap_grad_buffer(self.bucket[1])
 
     def wait(self):
         for i in (0, 1):
             if self.work[i] is not None:
                 self.work[i].wait()
                 self.work[i] = None
-        self.model.swap_grad_buffer(self.bucket[0])
-
-    def second_bucket(self):
-        return self.bucket[1]

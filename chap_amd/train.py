@@ -65,7 +65,7 @@ class VAT2d:
     def __init__(self, xi=10.0, epi=6.0, num_classes=4, ip=1, sign=False):
         self.xi, self.epi, self.num_classes, self.ip, self.sign = xi, epi, num_classes, ip, sign
 
-    def __call__(self, model, x, soft1, soft2, mask, losstype="kl", weight_dev=None, inject=None, accumulate_grad=True):
+    def __call__(self, model, x, soft1, soft2, mask, losstype="kl", weight_dev=None, inject=None, accumulate_grad=True, grad_buffer=None):
         if losstype != "kl":
             raise NotImplementedError("chap_amd VAT2d: adv_losstype=%r (kl built)" % losstype)
         inject = inject or {}
@@ -93,7 +93,7 @@ class VAT2d:
         ops.perturb(x, d, xa, alpha, mask=m, sign=self.sign)
         loss = torch.zeros(1, dtype=torch.float32, device=x.device)
         if accumulate_grad:
-            l1, l2 = model(xa, update_stats=False, drop_masks=inject.get("drop_VF"))
+            l1, l2 = model(xa, update_stats=False, drop_masks=inject.get("drop_VF"), grad_buffer=grad_buffer)
             g1, g2 = torch.empty_like(l1), torch.empty_like(l2)
             ops.kl_fwd_bwd((l1, l2), (soft1, soft2), loss, (g1, g2), gscale_dev=weight_dev)
             torch.autograd.backward([l1, l2], [g1, g2])
@@ -125,8 +125,13 @@ class ChapStep:
         self.cw_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         self.iter_num = 0
         self.world_size = world_size
-        self.grad_sync = None                   # set by parallel.DataParallelSync
+        self.grad_sync = None                   # parallel.DataParallelSync (world_size > 1)
         self._graph = None
+        # second gradient bucket: the VAT branch accumulates here, so it can run on its own stream beside the
+        # BCP branch (and, data-parallel, its all-reduce overlaps); the fused SGD sums both buckets
+        self.grad2 = torch.zeros_like(model.flat_buffers()[1])
+        self.concurrent = bool(a.get("concurrent", True))
+        self._side = torch.cuda.Stream(device=dev) if self.concurrent else None
 
     # ------------------------------------------------------------------ host-side schedule values
     def prepare(self, box_yx=None):
@@ -178,6 +183,20 @@ class ChapStep:
             ops.box_mix(img_b, uimg_b, net_input_mix[:lsub], self.box)       # img_b*mask + uimg_b*(1-mask)
             ops.box_mix(uimg_a, img_a, net_input_mix[lsub:], self.box)       # uimg_a*mask + img_a*(1-mask)
 
+        # ---- the VAT branch (:368-375) depends only on pass A: it runs on a side stream beside pass B and
+        #      accumulates its parameter gradients into the second bucket
+        main = torch.cuda.current_stream()
+        vat_loss = None
+        if a["adv_noise"]:
+            diff_mask = ops.diff_mask(pseudo_outputs1, pseudo_outputs2, knowledge, 4, a["topk1"])
+            if self.concurrent:
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    vat_loss = self.adv_loss(model, volume_batch, outputs_soft1, outputs_soft2, diff_mask, a["adv_losstype"],
+                                             weight_dev=self.cw_dev, inject=inject, grad_buffer=self.grad2)
+                    if self.grad_sync is not None:
+                        self.grad_sync.bucket_ready(1)
+
         # ---- pass B + the four mix_loss terms (:339-351)
         out_mix1, out_mix2 = model(net_input_mix, drop_masks=inject.get("drop_B"))
         d1, d2 = torch.empty_like(out_mix1), torch.empty_like(out_mix2)
@@ -197,22 +216,20 @@ class ChapStep:
         if self.grad_sync is not None:
             self.grad_sync.bucket_ready(0)
 
-        # ---- spatial adversarial perturbation (:368-375)
-        if a["adv_noise"]:
-            diff_mask = ops.diff_mask(pseudo_outputs1, pseudo_outputs2, knowledge, 4, a["topk1"])
+        if a["adv_noise"] and not self.concurrent:
             vat_loss = self.adv_loss(model, volume_batch, outputs_soft1, outputs_soft2, diff_mask, a["adv_losstype"],
-                                     weight_dev=self.cw_dev, inject=inject)
-        else:
+                                     weight_dev=self.cw_dev, inject=inject, grad_buffer=self.grad2)
+            if self.grad_sync is not None:
+                self.grad_sync.bucket_ready(1)
+        if self.concurrent and a["adv_noise"]:
+            main.wait_stream(self._side)
+        if vat_loss is None:
             vat_loss = torch.zeros(1, dtype=torch.float32, device=volume_batch.device)
         if self.grad_sync is not None:
-            self.grad_sync.bucket_ready(1)
             self.grad_sync.wait()
 
-        # ---- optimizer.step() (:381-383)
-        if self.grad_sync is not None:
-            self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad_sync.second_bucket())
-        else:
-            self.opt.step()
+        # ---- optimizer.step() (:381-383): sums both buckets, zeroes them
+        self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad2)
         return {"mix_losses": losses, "vat_loss": vat_loss}
 
     def step(self, volume_batch, label_batch, box_yx=None, inject=None):
