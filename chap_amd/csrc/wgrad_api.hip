@@ -12,13 +12,14 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     q->Cb = p->b.C;
     CHAP_CHECK_ARG(q->Ca % 16 == 0 && q->Cb % 8 == 0, "chap_wgrad: Ca=%d must be a multiple of 16, Cb=%d of 8", q->Ca, q->Cb);
     q->KC = (q->Ca >= 32 && q->Ca % 32 == 0) ? 32 : 16;
+    if (p->dtype == CHAP_F32 && p->ksize == 2) q->KC = 16;      // fp32 k2 s2 halos: two buffers of 32 channels exceed the 160 KiB LDS
     CHAP_CHECK_ARG(q->Ca % q->KC == 0, "chap_wgrad: Ca=%d not a multiple of %d", q->Ca, q->KC);
     q->taps = p->ksize * p->ksize * (p->dims == 3 ? p->ksize : 1);
-    const bool small_tile = (p->ksize == 2 && p->dims == 3);
+    const bool small_tile = (p->dims == 3 && p->ksize >= 2);   // 3D geometries use 4 x 16 tiles (MR = 1)
     const int TH = small_tile ? 4 : 8;
     q->ntiles = (long)p->N * p->D * cdiv(p->H, TH) * cdiv(p->W, 16);
     const long pairs = (long)(q->Ca / q->KC) * cdiv(q->Cb, 32);
-    long ns = 1024 / pairs;
+    long ns = 512 / pairs;       // persistent, pipelined blocks: ~2 per CU are enough; fewer splits = fewer slab bytes to reduce
     if (ns < 1) ns = 1;
     if (ns > q->ntiles) ns = q->ntiles;
     q->slab = (size_t)q->taps * q->Ca * q->Cb * sizeof(float);

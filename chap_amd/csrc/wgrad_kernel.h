@@ -18,66 +18,150 @@ template <typename T> __host__ __device__ constexpr int wg_psb() { return sizeof
 template <typename T, int KS, int ST, bool D3, int KC, int MR>
 __host__ __device__ constexpr size_t wgrad_lds_bytes() {
     typedef conv_geom<KS, ST, D3, MR> G;
-    return ((size_t)G::HP * pix_stride<T, KC>() + (size_t)G::TH * G::TW * wg_psb<T>()) * sizeof(T);
+    return 2 * ((size_t)G::HP * pix_stride<T, KC>() + (size_t)G::TH * G::TW * wg_psb<T>()) * sizeof(T)    // double-buffered A halo + B tile
+           + 3 * CONV_MAX_AFFINE_C * sizeof(float) + 4 * WG_BN * sizeof(float);                            // affine caches (A0, A1, B), db partials
 }
 
 __device__ __forceinline__ s16x4 lds_tr16(const bf16_t* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
 }
 
-template <typename T, int KS, int ST, bool D3, int KC, int MR>
+// Persistent blocks, one (A-chunk, B-chunk, split) each: the A halo and the B tile of tile i+1 are
+// fetched into registers while tile i runs on the MFMA pipe out of LDS (same scheme as conv_fwd_kernel).
+template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2>
 __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, float* __restrict__ ws, float* __restrict__ ws_db,
                                                     int nsplit, int Ca, int Cb) {
     typedef conv_geom<KS, ST, D3, MR> G;
-    constexpr int PS = pix_stride<T, KC>(), PSB = wg_psb<T>();
+    typedef typename frag<T>::type F;
+    constexpr int GPT = KC / 8, PS = pix_stride<T, KC>(), PSB = wg_psb<T>();
     constexpr int KCT = KC / 16, NTB = WG_BN / 16;
     constexpr int PAIRS = G::NTAPS * KCT, MAXP = (PAIRS + 3) / 4;
     constexpr int NKCH = G::TH * G::TW / 32;            // 32-pixel k-chunks per tile
+    constexpr int UNITS = (G::HP * GPT + 255) / 256;
+    constexpr int BUNITS = (G::TH * G::TW * (WG_BN / 8) + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    T* halo = (T*)smem;
-    T* btile = halo + (size_t)G::HP * PS;
+    T* halo0 = (T*)smem;
+    T* halo1 = halo0 + (size_t)G::HP * PS;
+    T* bt0 = halo1 + (size_t)G::HP * PS;
+    T* bt1 = bt0 + (size_t)G::TH * G::TW * PSB;
+    float* aff = (float*)(bt1 + (size_t)G::TH * G::TW * PSB);       // [A0 | A1 | B] x [scale | shift]
+    float* dbred = aff + 3 * CONV_MAX_AFFINE_C;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int split = blockIdx.x, chunk = blockIdx.y, nb = blockIdx.z;
     const int tiles_x = (P.W + G::TW - 1) / G::TW, tiles_y = (P.H + G::TH - 1) / G::TH;
     const long ntiles = (long)P.N * P.D * tiles_y * tiles_x;
+    const long my_tiles = split < ntiles ? (ntiles - split + nsplit - 1) / nsplit : 0;
+
+    const src_scalars s0 = make_scalars(P.a[0]);
+    const src_scalars s1 = make_scalars(P.na > 1 ? P.a[1] : P.a[0]);
+    const src_scalars sb = make_scalars(P.b);
+    const bool plainA = !ADD2 && P.a[0].scale == nullptr && !P.a[0].act && P.a[0].keep == nullptr && P.a[0].chan_mul == nullptr &&
+                        (P.na < 2 || (P.a[1].scale == nullptr && !P.a[1].act && P.a[1].keep == nullptr && P.a[1].chan_mul == nullptr));
+    const bool plainB = P.b.scale == nullptr && !P.b.act && P.b.keep == nullptr && P.b.chan_mul == nullptr;
+
+    // ---- one-time per thread: unit descriptors
+    unit_desc<UNITS> U;
+#pragma unroll
+    for (int j = 0; j < UNITS; ++j) {
+        const int u = threadIdx.x + 256 * j;
+        U.hzyx[j] = -1; U.rel[j] = 0; U.lds[j] = 0; U.c8[j] = 0;
+        if (u < G::HP * GPT) {
+            const int pix = u / GPT, cgl = u % GPT;
+            const int hx = pix % G::HW, hy = (pix / G::HW) % G::HH, hz = pix / (G::HW * G::HH);
+            U.hzyx[j] = (hz << 20) | (hy << 10) | hx;
+            U.rel[j] = (hz * P.IH + hy) * P.IW + hx;
+            U.lds[j] = pix * PS + cgl * 8;
+            U.c8[j] = cgl * 8;
+        }
+    }
+    int b_yx[BUNITS], b_rel[BUNITS], b_lds[BUNITS];     // B tile units: (row << 8 | col), pixel offset, LDS offset; channel = nb*32 + (tid % 4) * 8
+    const int bc8 = (threadIdx.x & (WG_BN / 8 - 1)) * 8;
+    const int cbB = nb * WG_BN + bc8;
+    const bool bchan_ok = cbB < Cb;
+#pragma unroll
+    for (int j = 0; j < BUNITS; ++j) {
+        const int u = threadIdx.x + 256 * j;
+        const int pix = u / (WG_BN / 8);
+        b_yx[j] = -1; b_rel[j] = 0; b_lds[j] = 0;
+        if (pix < G::TH * G::TW) {
+            const int row = pix / G::TW, col = pix % G::TW;
+            b_yx[j] = (row << 8) | col;
+            b_rel[j] = row * P.W + col;
+            b_lds[j] = pix * PSB + bc8;
+        }
+    }
+    // affine caches
+    for (int s = 0; s < 3; ++s) {
+        const chap_src_t& src = s == 2 ? P.b : P.a[s < P.na ? s : 0];
+        const bool has = src.scale != nullptr;
+        for (int c = threadIdx.x; c < src.C && c < CONV_MAX_AFFINE_C / 2; c += 256) {
+            aff[s * CONV_MAX_AFFINE_C + c] = has ? src.scale[c] : 1.f;
+            aff[s * CONV_MAX_AFFINE_C + CONV_MAX_AFFINE_C / 2 + c] = has ? src.shift[c] : 0.f;
+        }
+    }
 
     f32x4 acc[MAXP][NTB];
 #pragma unroll
     for (int i = 0; i < MAXP; ++i)
 #pragma unroll
         for (int t = 0; t < NTB; ++t) acc[i][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float dbacc = 0.f;
-
-    for (long tile = split; tile < ntiles; tile += nsplit) {
-        long b = tile;
-        const int tx = (int)(b % tiles_x); b /= tiles_x;
-        const int ty = (int)(b % tiles_y); b /= tiles_y;
-        const int z0 = (int)(b % P.D);     const int n = (int)(b / P.D);
-        const int x0 = tx * G::TW, y0 = ty * G::TH;
-        __syncthreads();                                   // previous tile's LDS reads are done
-        stage_halo<T, KS, ST, D3, KC, MR>(halo, P.a[0], P.a[1], P.na, P.combine, n, z0, y0, x0, P.ID, P.IH, P.IW, chunk);
-        for (int u = threadIdx.x; u < G::TH * G::TW * (WG_BN / 8); u += 256) {
-            const int pix = u / (WG_BN / 8), c8 = (u % (WG_BN / 8)) * 8;
-            const int yy = y0 + pix / G::TW, xx = x0 + pix % G::TW;
-            float v[8];
-            const int cb = nb * WG_BN + c8;
-            if (yy < P.H && xx < P.W && cb < Cb) {
-                const long gp = (((long)n * P.D + z0) * P.H + yy) * P.W + xx;
-                src_load8<T>(P.b, n, gp, cb, v);
-            } else {
+    float dbsum[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int j = 0; j < 8; ++j) dbsum[j] = 0.f;
+    const bool want_db = ws_db != nullptr && chunk == 0;
+
+    halo_regs<T, UNITS, ADD2> R;
+    F braw[BUNITS]; uint2 bkeep[BUNITS]; unsigned bok = 0;
+
+    auto issue = [&](long tile, int& n, int& z0, int& y0, int& x0) {
+        tile_coords<G::TH, G::TW>(tile, tiles_x, tiles_y, P.D, n, z0, y0, x0);
+        halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, s0, s1, P.ID, P.IH, P.IW, n, z0, y0, x0, chunk);
+        const long gp0 = (((long)n * P.D + z0) * P.H + y0) * P.W + x0;
+        const T* bb = (const T*)sb.ptr + gp0 * sb.ld + sb.coff + cbB;
+        const uint8_t* kb = sb.keep + gp0 * sb.C + cbB;
+        bok = 0;
+#pragma unroll
+        for (int j = 0; j < BUNITS; ++j) {
+            const int d = b_yx[j];
+            if (d >= 0 && bchan_ok && y0 + (d >> 8) < P.H && x0 + (d & 255) < P.W) {
+                bok |= 1u << j;
+                braw[j] = frag<T>::load(bb + b_rel[j] * sb.ld);
+                if (sb.has_keep) bkeep[j] = *(const uint2*)(kb + b_rel[j] * sb.C);
             }
-            st8(btile + pix * PSB + c8, v);
         }
-        __syncthreads();
-        if (ws_db != nullptr && chunk == 0 && threadIdx.x < WG_BN) {
-            float s = 0.f;
-            for (int pix = 0; pix < G::TH * G::TW; ++pix) s += elem<T>::get(btile[pix * PSB + threadIdx.x]);
-            dbacc += s;
+    };
+    auto commit = [&](T* halo, T* bt, int n) {
+        halo_commit<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, halo, s0, s1, aff, plainA, n, chunk);
+#pragma unroll
+        for (int j = 0; j < BUNITS; ++j) {
+            if (b_yx[j] < 0) continue;
+            T* dst = bt + b_lds[j];
+            if (!((bok >> j) & 1u)) { frag<T>::store(dst, frag<T>::zero()); continue; }
+            float v[8];
+            frag<T>::unpack(braw[j], v);
+            if (!plainB) lazy_transform(v, aff + 2 * CONV_MAX_AFFINE_C, cbB, sb.slope_eff, sb.has_keep, bkeep[j], sb.keep_scale,
+                                        sb.has_cm ? sb.chan_mul + (long)n * sb.C : nullptr);
+            if (want_db) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dbsum[k] += v[k];
+            }
+            if (plainB) frag<T>::store(dst, braw[j]); else st8(dst, v);
         }
+    };
+
+    int n = 0, z0 = 0, y0 = 0, x0 = 0;
+    if (my_tiles > 0) issue(split, n, z0, y0, x0);
+    __syncthreads();
+    if (my_tiles > 0) commit(halo0, bt0, n);
+    __syncthreads();
+
+    for (long k = 0; k < my_tiles; ++k) {
+        const T* halo = (k & 1) ? halo1 : halo0;
+        const T* btile = (k & 1) ? bt1 : bt0;
+        const bool has_next = k + 1 < my_tiles;
+        if (has_next) issue(split + (k + 1) * nsplit, n, z0, y0, x0);
 #pragma unroll 1
         for (int kc = 0; kc < NKCH; ++kc) {
             if constexpr (sizeof(T) == 2) {
@@ -127,6 +211,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
                 }
             }
         }
+        if (has_next) commit((k & 1) ? halo0 : halo1, (k & 1) ? bt0 : bt1, n);
+        __syncthreads();
     }
     // ---- partial slab: ws[split][tap][kc_global][kn_global]; lane holds rows 4g+j (kc), col l15 (kn) ----
     float* slab = ws + (long)split * G::NTAPS * Ca * Cb;
@@ -148,6 +234,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
             }
         }
     }
-    if (ws_db != nullptr && chunk == 0 && threadIdx.x < WG_BN && nb * WG_BN + threadIdx.x < Cb)
-        ws_db[(long)split * Cb + nb * WG_BN + threadIdx.x] = dbacc;
+    if (want_db) {
+        // threads with equal (tid % 4) hold the same 8 channels: shuffle over lanes 4,8,16,32 apart, then across waves via LDS
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = dbsum[j];
+            for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (lane < 4) dbred[wave * WG_BN + lane * 8 + j] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < WG_BN && nb * WG_BN + threadIdx.x < Cb)
+            ws_db[(long)split * Cb + nb * WG_BN + threadIdx.x] = dbred[threadIdx.x] + dbred[WG_BN + threadIdx.x] + dbred[2 * WG_BN + threadIdx.x] + dbred[3 * WG_BN + threadIdx.x];
+    }
 }
