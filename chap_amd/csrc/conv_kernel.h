@@ -191,13 +191,21 @@ __device__ __forceinline__ void halo_issue(halo_regs<T, UNITS, ADD2>& R, const u
     }
 }
 
-// affine cache layout in LDS: [src][scale | shift][CONV_MAX_AFFINE_C/2] (identity when a source has none)
+// affine cache layout in LDS: [src][scale | shift][CONV_MAX_AFFINE_C/2] (identity when a source has none).
+// Packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32, 2 elements per VALU instruction): the commit phase is
+// VALU-issue-bound.  leaky(z) = max(z, slope*z) for 0 <= slope <= 1 (slope_eff = 1: no activation).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void lazy_transform(float v[8], const float* aff, int c, float slope_eff, bool has_keep, uint2 keep, float keep_scale,
                                                const float* cm) {
+    const f32x2 sl = {slope_eff, slope_eff};
+    const f32x2* a2 = (const f32x2*)(aff + c);
+    const f32x2* b2 = (const f32x2*)(aff + CONV_MAX_AFFINE_C / 2 + c);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float z = fmaf(v[j], aff[c + j], aff[CONV_MAX_AFFINE_C / 2 + c + j]);
-        v[j] = z > 0.f ? z : z * slope_eff;
+    for (int j = 0; j < 4; ++j) {
+        f32x2 z = {v[2 * j], v[2 * j + 1]};
+        z = z * a2[j] + b2[j];
+        const f32x2 m = z * sl;
+        v[2 * j] = fmaxf(z.x, m.x); v[2 * j + 1] = fmaxf(z.y, m.y);
     }
     if (has_keep) {
 #pragma unroll
