@@ -417,6 +417,7 @@ extern "C" int chap_upsample2x_bwd(const chap_upsample_bwd_params* p, void* stre
 // Backward through the lazy activation (+ pooled consumer) and training-mode BatchNorm.
 // Thread = (pixel, 8 channels); a block covers 256/C8 pixels per step, grid-stride; per-channel
 // partial sums are reduced over the block in LDS and flushed with one atomic per channel.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int ACT_BWD_REPS = CHAP_ACT_BWD_REPS;   // sums layout: [REPS][2][C]
 
 template <typename T>
@@ -448,12 +449,19 @@ __device__ __forceinline__ void act_bwd_dz(const chap_act_bwd_params& P, const f
         }
     }
     // a = keep*ks*cm*leaky(z), z = scale*raw+shift  ->  da/dz = keep*ks*cm*(z>0 ? 1 : slope)
+    if (s.act) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float z = fmaf(raw[j], sa[j], sb[j]);
-        float d = gsum[j];
-        if (s.act) d *= (z > 0.f ? 1.f : s.slope);
-        dz[j] = d;
+        for (int j = 0; j < 4; ++j) {          // packed fp32: z = raw*scale + shift (v_pk_fma_f32), dz = g * f (v_pk_mul_f32)
+            const f32x2 r2 = {raw[2 * j], raw[2 * j + 1]}, a2 = {sa[2 * j], sa[2 * j + 1]}, b2 = {sb[2 * j], sb[2 * j + 1]};
+            const f32x2 z = r2 * a2 + b2;
+            const f32x2 f = {z.x > 0.f ? 1.f : s.slope, z.y > 0.f ? 1.f : s.slope};
+            const f32x2 g2 = {gsum[2 * j], gsum[2 * j + 1]};
+            const f32x2 d = g2 * f;
+            dz[2 * j] = d.x; dz[2 * j + 1] = d.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dz[j] = gsum[j];
     }
     if (s.keep) {
         const uint2 m = *(const uint2*)(s.keep + pix * C + c8);
@@ -478,13 +486,15 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
     const long npix = (long)P.N * P.D * P.H * P.W;
     const int c8 = (threadIdx.x % C8) * 8;
     const int prow = threadIdx.x / C8, PPB = 256 / C8;      // C8 in {2,4,8,...,32} divides 256
-    float s0[8], s1[8], mean[8], istd[8], k0[8], k1[8], k2[8], sa[8], sb[8];
+    float s0[8], s1[8], mean[8], istd[8], k0[8], k1[8], k2[8], sa[8], sb[8], cB[8], cC[8], cM[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; sa[j] = 1.f; sb[j] = 0.f; }
     if (P.r.scale) { ld8(P.r.scale + c8, sa); ld8(P.r.shift + c8, sb); }      // per-channel constants: loaded once
 #pragma unroll
     for (int j = 0; j < 8; ++j) { k0[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; mean[j] = 0.f; istd[j] = 1.f; }
     if (P.bn) { ld8(P.mean + c8, mean); ld8(P.invstd + c8, istd); }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { cB[j] = 0.f; cC[j] = 0.f; cM[j] = -mean[j] * istd[j]; }      // xhat = raw*istd + cM
     if (APPLY) {
         if (P.bn == 1) {                               // training-mode BatchNorm backward
             // compact the replicas of the reduce phase cooperatively into LDS (2C x REPS loads per block)
@@ -506,6 +516,12 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
             for (int j = 0; j < 8; ++j) { a0[j] = red[c8 + j]; a1[j] = red[C + c8 + j]; }
 #pragma unroll
             for (int j = 0; j < 8; ++j) { k0[j] = gm[j] * istd[j]; k1[j] = a0[j] / P.count; k2[j] = a1[j] / P.count; }
+            // g = k0*(dz - k1 - xhat*k2), xhat = raw*istd - mean*istd  ==  dz*k0 + raw*cB + cC  (two FMAs per element)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                cB[j] = -istd[j] * k0[j] * k2[j];
+                cC[j] = -k0[j] * k1[j] + mean[j] * istd[j] * k0[j] * k2[j];
+            }
         } else if (P.r.scale) {                        // fixed affine (eval-mode BN): dz/draw = scale
             ld8(P.r.scale + c8, k0);
         }
@@ -524,12 +540,23 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
             act_bwd_dz<T>(P, sa, sb, n, pix, y, x, c8, raw, dz);
             if (!APPLY) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { s0[j] += dz[j]; s1[j] += dz[j] * (raw[j] - mean[j]) * istd[j]; }
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 d = {dz[2 * j], dz[2 * j + 1]}, r2 = {raw[2 * j], raw[2 * j + 1]};
+                    const f32x2 i2 = {istd[2 * j], istd[2 * j + 1]}, m2 = {cM[2 * j], cM[2 * j + 1]};
+                    const f32x2 xh = r2 * i2 + m2;
+                    f32x2 a = {s0[2 * j], s0[2 * j + 1]}, b = {s1[2 * j], s1[2 * j + 1]};
+                    a = a + d; b = d * xh + b;
+                    s0[2 * j] = a.x; s0[2 * j + 1] = a.y; s1[2 * j] = b.x; s1[2 * j + 1] = b.y;
+                }
             } else {
                 float o[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    o[j] = P.bn == 1 ? k0[j] * (dz[j] - k1[j] - (raw[j] - mean[j]) * istd[j] * k2[j]) : dz[j] * k0[j];
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 d = {dz[2 * j], dz[2 * j + 1]}, r2 = {raw[2 * j], raw[2 * j + 1]};
+                    const f32x2 A = {k0[2 * j], k0[2 * j + 1]}, B = {cB[2 * j], cB[2 * j + 1]}, Cc = {cC[2 * j], cC[2 * j + 1]};
+                    const f32x2 r = d * A + (r2 * B + Cc);         // bn != 1: cB = cC = 0 -> dz*k0
+                    o[2 * j] = r.x; o[2 * j + 1] = r.y;
+                }
                 st8((T*)P.gout + pix * C + c8, o);
             }
         }
