@@ -37,6 +37,8 @@ class Op:
         self.slope = kw.get("slope", 0.0)  # activation after BN (when bn is set)
         self.head = kw.get("head", False)  # planar fp32 logits
         self.drop = kw.get("drop")         # (site, p, 'elem' | 'chan') applied to the OUTPUT value
+        self.branch = kw.get("branch", 0)            # 0 = shared trunk (encoder); k > 0 = k-th decoder: decoders run on
+                                                    # parallel streams (they only meet again in the encoder's backward)
         self.inorm = kw.get("inorm", False)          # InstanceNorm (no affine) + ReLU after the conv: batch-of-one statistics
         self.half_pixel = kw.get("half_pixel", False)  # 'up': align_corners=False
 
@@ -75,11 +77,28 @@ class Executor:
         self.m, self.prog = module, program
         self._packed = {}          # dtype -> {bufs, table, ...}: packed weights + chap_pack_multi entry table
         self._ident = {}           # C -> (ones, zeros) for InstanceNorm (no affine)
+        self._sides = {}           # parent stream -> forked stream for the second decoder
         self.has_inorm = any(op.inorm for op in program.ops)
 
     # ---------------------------------------------------------------- parameters
     def _sd(self):
         return self.m._tensors()   # name -> tensor (params and buffers, fp32, on device)
+
+    def _side_stream(self, parent):
+        """Forked stream for the second decoder, one per parent stream (pass B on the main stream and the VAT
+        branch on its own stream may both be inside this executor).  Eager mode only: a second level of
+        fork/join inside a captured HIP graph crashes hipStreamEndCapture on ROCm 7.2, so under capture the
+        decoders run back to back (the pass-B / VAT fork of ChapStep is the one level that is captured)."""
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        key = parent.cuda_stream
+        st = self._sides.get(key)
+        if st is None:
+            if len(self._sides) >= 8:
+                return None
+            st = torch.cuda.Stream(device=parent.device)
+            self._sides[key] = st
+        return st
 
     def _pack_kinds(self, op):
         if op.kind == "conv":
@@ -154,7 +173,12 @@ class Executor:
             return t
 
         outs = {}
-        for op in prog.ops:
+        cur_stream = torch.cuda.current_stream()
+        branches = sorted({op.branch for op in prog.ops})
+        side = self._side_stream(cur_stream) if len(branches) > 2 else None
+
+        def run_op(op):
+            nonlocal apos
             k = op.kind
             if k == "pool":
                 src = vals[op.srcs[0]]
@@ -166,7 +190,7 @@ class Executor:
                 vals[op.out], vdims[op.out] = Lazy(out), (od, h // 2, w // 2)
                 if save:
                     S.pool_idx[op.out] = idx
-                continue
+                return
             if k == "up":
                 src = vals[op.srcs[0]]
                 d, h, w = vdims[op.srcs[0]]
@@ -174,7 +198,7 @@ class Executor:
                 out = torch.empty(N, od, 2 * h, 2 * w, src.C, dtype=dtype, device=dev)
                 ops.upsample2x(src, out, dims=dims, half_pixel=op.half_pixel)
                 vals[op.out], vdims[op.out] = Lazy(out), (od, 2 * h, 2 * w)
-                continue
+                return
             # ---- convolutions
             stats = take(STATS_REPS * 2 * op.cout) if ((op.bn and train) or op.inorm) else None
             bias = sd[op.b] if op.b else None
@@ -199,7 +223,7 @@ class Executor:
                                  combine=op.combine, out_planar=True, out_f32=True)
                     outs[op.out] = out
                     vdims[op.out] = gd
-                    continue
+                    return
                 if k == "deconv":
                     od = (2 * gd[0] if dims == 3 else gd[0], 2 * gd[1], 2 * gd[2])
                     out = torch.empty((N,) + od + (op.cout,), dtype=dtype, device=dev)
@@ -254,6 +278,24 @@ class Executor:
                     if cm is not None:
                         lz.chan_mul = cm
             vals[op.out] = lz
+        # ---- schedule: trunk, then the decoders side by side (second decoder on a forked stream)
+        for op in prog.ops:
+            if op.branch == 0:
+                run_op(op)
+        if side is not None:
+            side.wait_stream(cur_stream)
+            with torch.cuda.stream(side):
+                for op in prog.ops:
+                    if op.branch >= 2:
+                        run_op(op)
+            for op in prog.ops:
+                if op.branch == 1:
+                    run_op(op)
+            cur_stream.wait_stream(side)
+        else:
+            for op in prog.ops:
+                if op.branch != 0:
+                    run_op(op)
         logits = [outs[h] for h in prog.heads]
         extras = []
         for name in want:
@@ -289,14 +331,15 @@ class Executor:
             spos[0] += n
             return t
 
-        for op in reversed(prog.ops):
+        def bwd_op(op):
+            nonlocal dx
             k = op.kind
             if k == "pool":
                 c = contrib.get(op.out)
                 if c:
                     assert len(c) == 1 and c[0][1] == 0
                     pooled[op.srcs[0]] = (c[0][0], S.pool_idx[op.out])
-                continue
+                return
             if k == "up":
                 c = contrib.get(op.out)
                 if c:
@@ -306,12 +349,12 @@ class Executor:
                     o = torch.empty(N, d, h, w, src.C, dtype=dtype, device=dev)
                     ops.upsample2x_bwd(c[0][0], c[0][1], src.C, o, dims=dims)
                     contrib.setdefault(op.srcs[0], []).append((o, 0))
-                continue
+                return
             # ---- gradient w.r.t. the raw output of this conv
             if op.head:
                 dl = head_g.get(op.out)
                 if dl is None:
-                    continue
+                    return
                 gd = S.dims[op.out]
                 g16 = torch.empty((N,) + gd + (16,), dtype=dtype, device=dev)
                 ops.planar_to_cl(dl, g16, cpad=16)
@@ -321,7 +364,7 @@ class Executor:
                 c = contrib.get(op.out)
                 pl = pooled.get(op.out)
                 if not c and pl is None:
-                    continue
+                    return
                 v = S.vals[op.out]
                 gd = S.dims[op.out]
                 kn_valid = 0
@@ -358,7 +401,7 @@ class Executor:
                 ops.conv_c1_bwd(gt, sd[op.w], S.x.view(N, D, H, W), dims=dims,
                                 dx=dx.view(N, D, H, W) if need_dx else None,
                                 dw=gr[op.w] if need_wgrad else None, db=gr[op.b] if (need_wgrad and op.b) else None)
-                continue
+                return
             srcs = [S.vals[s] for s in op.srcs]
             sd_, sh_, sw_ = S.dims[op.srcs[0]]
             ctot = sum(s.C for s in srcs) if op.combine == 0 else srcs[0].C
@@ -396,6 +439,26 @@ class Executor:
                     dsrc = torch.empty(N, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                     ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(N, sd_, sh_, sw_), in_dims=fine, ksize=2, stride=2, dims=dims)
                     self._scatter(contrib, op, srcs, dsrc)
+        # ---- schedule: the decoders' backward passes side by side, then the shared trunk
+        cur_stream = torch.cuda.current_stream()
+        rev = list(reversed(prog.ops))
+        side = self._side_stream(cur_stream) if len({op.branch for op in prog.ops}) > 2 else None
+        if side is not None:
+            side.wait_stream(cur_stream)
+            with torch.cuda.stream(side):
+                for op in rev:
+                    if op.branch >= 2:
+                        bwd_op(op)
+            for op in rev:
+                if op.branch == 1:
+                    bwd_op(op)
+            cur_stream.wait_stream(side)
+            for op in rev:
+                if op.branch == 0:
+                    bwd_op(op)
+        else:
+            for op in rev:
+                bwd_op(op)
         return dx
 
     def _needs_src_grad(self, op, need_dx):

@@ -64,7 +64,8 @@ def build_program(n_class, decoders, enc_root="encoder"):
         ops.append(Op("pool", "p%d" % i, ["e%d" % (i - 1)]))
         _block_ops(ops, "%s.down%d.maxpool_conv.1.conv_conv" % (enc_root, i), ["p%d" % i], "e%d" % i, FT[i - 1], FT[i], DROP[i])
     heads = []
-    for root, bilinear in decoders:
+    for bi, (root, bilinear) in enumerate(decoders):
+        first_dec_op = len(ops)
         x = "e4"
         for k in range(1, 5):
             c1, c2 = FT[5 - k], FT[4 - k]
@@ -81,6 +82,8 @@ def build_program(n_class, decoders, enc_root="encoder"):
         ops.append(Op("conv", root + ".logits", [x], ksize=3, w=root + ".out_conv.weight", b=root + ".out_conv.bias",
                       cin=FT[0], cout=n_class, head=True))
         heads.append(root + ".logits")
+        for op in ops[first_dec_op:]:
+            op.branch = bi + 1          # decoders are independent of each other: parallel streams
     return Program(2, ops, heads)
 
 

@@ -96,7 +96,8 @@ def build_program(n_classes, nf, decoders, has_dropout):
             x = "d%d" % (i + 1)
         c = co
     heads = []
-    for root, up_type in decoders:
+    for bi, (root, up_type) in enumerate(decoders):
+        first_dec_op = len(ops)
         x = "b5"
         for k, (upn, blk, n) in enumerate(DEC):
             cin, cout = nf * (2 ** (4 - k)), nf * (2 ** (3 - k))
@@ -113,6 +114,8 @@ def build_program(n_classes, nf, decoders, has_dropout):
             x = out
         ops.append(Op("conv", root + ".logits", [x], ksize=1, w=root + ".out_conv.weight", b=root + ".out_conv.bias", cin=nf, cout=n_classes, head=True))
         heads.append(root + ".logits")
+        for op in ops[first_dec_op:]:
+            op.branch = bi + 1
     return Program(3, ops, heads)
 
 
