@@ -175,6 +175,9 @@ def dominant_kernel_roofline_3d(dtype, N, sp):
 
 def main():
     args = parse()
+    # Libraries (RCCL prints a version banner) must not pollute stdout: the contract is ONE JSON line there.
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -184,8 +187,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    force_dp = os.environ.get("CHAP_FORCE_DP") == "1"       # exercise the RCCL path with a 1-rank group (1-GPU box)
+    if world > 1 or force_dp:
         import torch.distributed as dist
+        if force_dp and "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"))
         dist.init_process_group("nccl", device_id=dev)
 
     from chap_amd.networks import DualDecoder, DualDecoder3d
@@ -204,15 +210,15 @@ def main():
     else:
         model = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(dev).train().set_compute_dtype(dtype)
         step = ChapStep(model, dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters), world_size=world)
-    if world > 1:
+    if dist is not None:
         from chap_amd.parallel import DataParallelSync
-        step.grad_sync = DataParallelSync(model.flat_buffers()[1], step.grad2, dist)
+        step.grad_sync = DataParallelSync(step.grad_both, dist)
     if d3:
         vol, lab = ots.synthetic_batch_3d(1337 + rank, B // 2, B - B // 2, *sp)
     else:
         vol, lab = ots.synthetic_batch(1337 + rank, B // 2, B - B // 2, H, H)    # each rank: its own shard (weak scaling)
     vol, lab = vol.to(dev), lab.to(dev)
-    use_graph = (not args.no_graph) and world == 1
+    use_graph = not args.no_graph
     log("model + data ready (B=%d, %s, %s)" % (B, "x".join(map(str, sp)), args.dtype))
     if use_graph:
         step.capture(vol, lab, warmup=2)
@@ -265,7 +271,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, B, sp)
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -2,36 +2,28 @@
 
 The reference has no distributed code; this is the build's own design:
 each rank runs the whole iteration on its own (labeled + unlabeled) shard -- BatchNorm statistics
-and Dice sums stay per replica (DDP semantics) -- and the ONLY exchange is a sum of the flat fp32
-gradient buffer, split in two buckets so that it overlaps with compute:
+and Dice sums stay per replica (DDP semantics) -- and the ONLY exchange is a sum of the gradients.
 
-  bucket 0  gradients of the BCP (mix_loss) backward, all-reduced asynchronously while the VAT
-            power-iteration and final passes run (they read the not-yet-updated weights);
-  bucket 1  gradients of the VAT final backward, all-reduced right after it.
-
-The fused SGD kernel then consumes (bucket0 + bucket1) * (1/world).  Payloads are 10.3 MB (2D) /
-49.4 MB (3D) of fp32, so the exchange is latency/per-link bound: one flat buffer per bucket, no
-per-tensor collectives.
+The two gradient buckets of an iteration (bucket 0: BCP / mix_loss backward, bucket 1: VAT final
+backward; they are produced concurrently on two streams) are the two halves of ONE contiguous fp32
+buffer, so the exchange is a single all-reduce of 2 x 10.3 MB (2D) / 2 x 49.4 MB (3D): latency / per-link
+bound on the xGMI mesh, hence one flat collective instead of per-tensor ones.  The fused SGD kernel then
+consumes (bucket0 + bucket1) * (1/world).  With HIP-graph replay the iteration is two graphs
+(compute, optimizer) with the collective in between, so RCCL never has to be captured.
 """
 import torch
 
 
 class DataParallelSync:
-    """bucket 0 = the model's own flat gradient buffer (BCP backward), bucket 1 = the second buffer the
-    VAT branch accumulates into (ChapStep.grad2)."""
+    def __init__(self, both_buckets, dist, group=None):
+        self.buf, self.dist, self.group = both_buckets, dist, group
+        self.work = None
 
-    def __init__(self, bucket0, bucket1, dist, group=None):
-        self.dist, self.group = dist, group
-        self.bucket = [bucket0, bucket1]
-        self.work = [None, None]
-
-    def bucket_ready(self, i):
-        """All gradients of bucket i have been enqueued on the current stream: start its all-reduce (async:
-        it overlaps whatever is enqueued next)."""
-        self.work[i] = self.dist.all_reduce(self.bucket[i], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+    def start(self):
+        """All gradients have been enqueued on the current stream: start the (asynchronous) all-reduce."""
+        self.work = self.dist.all_reduce(self.buf, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def wait(self):
-        for i in (0, 1):
-            if self.work[i] is not None:
-                self.work[i].wait()
-                self.work[i] = None
+        if self.work is not None:
+            self.work.wait()
+            self.work = None

@@ -129,7 +129,10 @@ class ChapStep:
         self._graph = None
         # second gradient bucket: the VAT branch accumulates here, so it can run on its own stream beside the
         # BCP branch (and, data-parallel, its all-reduce overlaps); the fused SGD sums both buckets
-        self.grad2 = torch.zeros_like(model.flat_buffers()[1])
+        n = model.flat_buffers()[1].numel()
+        self.grad_both = torch.zeros(2 * n, dtype=torch.float32, device=dev)     # [bucket 0 | bucket 1], one all-reduce
+        model.swap_grad_buffer(self.grad_both[:n])
+        self.grad2 = self.grad_both[n:]
         self.concurrent = bool(a.get("concurrent", True))
         self._side = torch.cuda.Stream(device=dev) if self.concurrent else None
 
@@ -153,7 +156,15 @@ class ChapStep:
         return lr_
 
     # ------------------------------------------------------------------ the device work
-    def device_step(self, volume_batch, label_batch, inject=None):
+    def exchange_and_update(self):
+        """(data-parallel) all-reduce of both gradient buckets, then optimizer.step() (:381-383): the fused SGD
+        sums the buckets, scales by 1/world and zeroes them."""
+        if self.grad_sync is not None:
+            self.grad_sync.start()
+            self.grad_sync.wait()
+        self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad2)
+
+    def device_step(self, volume_batch, label_batch, inject=None, update=True):
         a, model = self.args, self.model
         inject = inject or {}
         nc = a["num_classes"]
@@ -194,8 +205,6 @@ class ChapStep:
                 with torch.cuda.stream(self._side):
                     vat_loss = self.adv_loss(model, volume_batch, outputs_soft1, outputs_soft2, diff_mask, a["adv_losstype"],
                                              weight_dev=self.cw_dev, inject=inject, grad_buffer=self.grad2)
-                    if self.grad_sync is not None:
-                        self.grad_sync.bucket_ready(1)
 
         # ---- pass B + the four mix_loss terms (:339-351)
         out_mix1, out_mix2 = model(net_input_mix, drop_masks=inject.get("drop_B"))
@@ -213,23 +222,16 @@ class ChapStep:
             ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, iw, pw, acc, dl)
             losses.append(loss3)
         torch.autograd.backward([out_mix1, out_mix2], [d1, d2])
-        if self.grad_sync is not None:
-            self.grad_sync.bucket_ready(0)
 
         if a["adv_noise"] and not self.concurrent:
             vat_loss = self.adv_loss(model, volume_batch, outputs_soft1, outputs_soft2, diff_mask, a["adv_losstype"],
                                      weight_dev=self.cw_dev, inject=inject, grad_buffer=self.grad2)
-            if self.grad_sync is not None:
-                self.grad_sync.bucket_ready(1)
         if self.concurrent and a["adv_noise"]:
             main.wait_stream(self._side)
         if vat_loss is None:
             vat_loss = torch.zeros(1, dtype=torch.float32, device=volume_batch.device)
-        if self.grad_sync is not None:
-            self.grad_sync.wait()
-
-        # ---- optimizer.step() (:381-383): sums both buckets, zeroes them
-        self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad2)
+        if update:
+            self.exchange_and_update()
         return {"mix_losses": losses, "vat_loss": vat_loss}
 
     def step(self, volume_batch, label_batch, box_yx=None, inject=None):
@@ -258,11 +260,19 @@ class ChapStep:
         self.model._rng.reset_counter()
         g = torch.cuda.CUDAGraph()
         self.prepare()
+        dp = self.grad_sync is not None
         with torch.cuda.graph(g):
             self.model._rng.seed_dev.add_(1)
-            self._static_out = self.device_step(self._static_v, self._static_l)
+            self._static_out = self.device_step(self._static_v, self._static_l, update=not dp)
+        self._graph, self._graph_opt = g, None
+        if dp:          # data-parallel: [compute graph] -> RCCL all-reduce (eager) -> [optimizer graph]
+            self.grad_sync.start()
+            self.grad_sync.wait()
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2, pool=g.pool()):
+                self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad2)
+            self._graph_opt = g2
         self.finish()
-        self._graph = g
         return g
 
     def replay(self, volume_batch, label_batch, box_yx=None):
@@ -270,5 +280,9 @@ class ChapStep:
         self._static_l.copy_(label_batch, non_blocking=True)
         self.prepare(box_yx)
         self._graph.replay()
+        if self._graph_opt is not None:
+            self.grad_sync.start()
+            self.grad_sync.wait()
+            self._graph_opt.replay()
         self.finish()
         return self._static_out

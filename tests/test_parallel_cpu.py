@@ -16,15 +16,13 @@ def _worker(rank, world, port, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n = 1003
-    b0, b1 = torch.zeros(n), torch.zeros(n)
-    sync = DataParallelSync(b0, b1, dist)
+    both = torch.zeros(2 * n)
+    b0, b1 = both[:n], both[n:]         # bucket 0 = model gradient buffer, bucket 1 = VAT branch
+    sync = DataParallelSync(both, dist)
     g = torch.Generator().manual_seed(100 + rank)
-    bcp = torch.randn(n, generator=g)
-    vat = torch.randn(n, generator=g)
-    b0 += bcp                           # "BCP backward" accumulates into bucket 0
-    sync.bucket_ready(0)
-    b1 += vat                           # "VAT backward" accumulates into bucket 1 while bucket 0 is in flight
-    sync.bucket_ready(1)
+    b0 += torch.randn(n, generator=g)   # "BCP backward"
+    b1 += torch.randn(n, generator=g)   # "VAT backward" (concurrent branch)
+    sync.start()
     sync.wait()
     total = (b0 + b1) / world           # what the fused SGD consumes: (grad + grad2) * grad_scale
     torch.save(total, os.path.join(out, "r%d.pt" % rank))
