@@ -261,7 +261,8 @@ class ChapStep:
         g = torch.cuda.CUDAGraph()
         self.prepare()
         dp = self.grad_sync is not None
-        with torch.cuda.graph(g):
+        # thread_local: the RCCL watchdog thread polls events while we capture (global mode would abort on that)
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self.model._rng.seed_dev.add_(1)
             self._static_out = self.device_step(self._static_v, self._static_l, update=not dp)
         self._graph, self._graph_opt = g, None
@@ -269,7 +270,7 @@ class ChapStep:
             self.grad_sync.start()
             self.grad_sync.wait()
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g.pool()):
+            with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode="thread_local"):
                 self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad2)
             self._graph_opt = g2
         self.finish()
