@@ -123,7 +123,7 @@ class KlParams(C.Structure):
 
 
 class L2NormParams(C.Structure):
-    _fields_ = [("in_", _vp), ("out", _vp), ("N", _i32), ("P", _i32), ("eps", _f32)]
+    _fields_ = [("in_", _vp), ("out", _vp), ("N", _i32), ("P", _i32), ("eps", _f32), ("ws", _vp)]
 
 
 class AxpyParams(C.Structure):

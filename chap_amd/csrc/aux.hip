@@ -2,24 +2,32 @@
 // spatial perturbation mask (avg-pool + per-sample top-k by radix select), fused SGD.
 #include "common.h"
 
-// ---- per-sample L2 normalise: one 1024-thread block per sample --------------------------------
-__global__ __launch_bounds__(1024) void l2norm_kernel(const chap_l2norm_params P) {
-    __shared__ float red[16];
-    const float* x = P.in + (long)blockIdx.x * P.P;
-    float* o = P.out + (long)blockIdx.x * P.P;
+// ---- per-sample L2 normalise: (sample, slice) blocks accumulate sum of squares, then scale -------------------
+__global__ __launch_bounds__(256) void l2norm_sumsq_kernel(const float* __restrict__ in, float* __restrict__ ss, int P) {
+    __shared__ float red[4];
+    const float* x = in + (long)blockIdx.y * P;
     float s = 0.f;
-    for (int i = threadIdx.x; i < P.P; i += 1024) { const float v = x[i]; s += v * v; }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) { const float v = x[i]; s += v * v; }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    float t = 0.f;
-    for (int i = 0; i < 16; ++i) t += red[i];
-    const float inv = 1.f / (sqrtf(t) + P.eps);
-    for (int i = threadIdx.x; i < P.P; i += 1024) o[i] = x[i] * inv;
+    if (threadIdx.x == 0) atomicAdd(&ss[blockIdx.y], (red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ __launch_bounds__(256) void l2norm_scale_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ ss, int P, float eps) {
+    const float inv = 1.f / (sqrtf(ss[blockIdx.y]) + eps);
+    const float* x = in + (long)blockIdx.y * P;
+    float* o = out + (long)blockIdx.y * P;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) o[i] = x[i] * inv;
 }
 extern "C" int chap_l2_normalize(const chap_l2norm_params* p, void* stream) {
-    CHAP_CHECK_ARG(p && p->in && p->out && p->N > 0 && p->P > 0, "chap_l2_normalize: bad argument");
-    hipLaunchKernelGGL(l2norm_kernel, dim3(p->N), dim3(1024), 0, (hipStream_t)stream, *p);
+    CHAP_CHECK_ARG(p && p->in && p->out && p->ws && p->N > 0 && p->P > 0, "chap_l2_normalize: bad argument (ws = N floats)");
+    hipStream_t s = (hipStream_t)stream;
+    int bx = (p->P + 256 * 8 - 1) / (256 * 8);
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    (void)hipMemsetAsync(p->ws, 0, sizeof(float) * p->N, s);
+    hipLaunchKernelGGL(l2norm_sumsq_kernel, dim3(bx, p->N), dim3(256), 0, s, p->in, p->ws, p->P);
+    hipLaunchKernelGGL(l2norm_scale_kernel, dim3(bx, p->N), dim3(256), 0, s, p->in, p->out, (const float*)p->ws, p->P, p->eps);
     CHAP_LAUNCH_CHECK("chap_l2_normalize");
     return CHAP_OK;
 }
@@ -138,10 +146,11 @@ __global__ void diffmask_pool_kernel(const chap_diffmask_params P) {
         P.pooled_ws[i] = s / (float)(P.scale * P.scale);
     }
 }
-// one block per sample: radix-select the k-th largest pooled value (non-negative floats order like
-// their bit patterns), then write the mask.
-__global__ __launch_bounds__(1024) void diffmask_select_kernel(const chap_diffmask_params P) {
-    __shared__ unsigned cnt, s_prefix;
+// one block per sample: radix-select (8 bits per pass, 256-bin LDS histogram) the k-th largest pooled value
+// (non-negative floats order like their bit patterns), then a second kernel writes the mask.
+__global__ __launch_bounds__(1024) void diffmask_select_kernel(const chap_diffmask_params P, float* thr_out) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix;
     __shared__ int s_rem;
     const int PH = P.H / P.scale, PW = P.W / P.scale, M = PH * PW;
     const int n = blockIdx.x;
@@ -149,31 +158,35 @@ __global__ __launch_bounds__(1024) void diffmask_select_kernel(const chap_diffma
     int k = (int)(P.topk * (float)M);
     if (k < 1) k = 1;
     if (threadIdx.x == 0) { s_prefix = 0; s_rem = k; }
-    __syncthreads();
-    for (int bit = 31; bit >= 0; --bit) {
-        if (threadIdx.x == 0) cnt = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
         __syncthreads();
-        const unsigned want = s_prefix | (1u << bit);
-        const unsigned maskhi = ~((1u << bit) - 1u);
-        unsigned c = 0;
+        const unsigned prefix = s_prefix;
+        const unsigned himask = shift == 24 ? 0u : ~((1u << (shift + 8)) - 1u);
         for (int i = threadIdx.x; i < M; i += 1024) {
             float f = v[i]; if (f < 0.f) f = 0.f;
-            if ((__float_as_uint(f) & maskhi) == want) ++c;
+            const unsigned u = __float_as_uint(f);
+            if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
         }
-        if (c) atomicAdd(&cnt, c);
         __syncthreads();
-        if (threadIdx.x == 0) { if ((int)cnt >= s_rem) s_prefix = want; else s_rem -= (int)cnt; }
+        if (threadIdx.x == 0) {
+            int rem = s_rem, b = 255;
+            for (; b > 0; --b) { if ((int)hist[b] >= rem) break; rem -= (int)hist[b]; }
+            s_rem = rem;
+            s_prefix = prefix | ((unsigned)b << shift);
+        }
         __syncthreads();
     }
-    const unsigned prefix = s_prefix;
-    const float thr = __uint_as_float(prefix);
-    const long base = (long)n * P.H * P.W;
-    for (int i = threadIdx.x; i < P.H * P.W; i += 1024) {
-        const int y = i / P.W, x = i % P.W;
-        float f = v[(y / P.scale) * PW + x / P.scale]; if (f < 0.f) f = 0.f;
-        const bool sel = f >= thr;
-        const bool diff = P.p1[base + i] != P.p2[base + i];
-        P.out[base + i] = (sel || diff) ? 1.f : 0.f;
+    if (threadIdx.x == 0) thr_out[n] = __uint_as_float(s_prefix);
+}
+__global__ void diffmask_write_kernel(const chap_diffmask_params P, const float* thr) {
+    const int PW = P.W / P.scale, M = (P.H / P.scale) * PW;
+    const long total = (long)P.N * P.H * P.W;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const unsigned ui = (unsigned)i;
+        const int x = (int)(ui % (unsigned)P.W), y = (int)((ui / (unsigned)P.W) % (unsigned)P.H), n = (int)(ui / (unsigned)(P.W * P.H));
+        float f = P.pooled_ws[(long)n * M + (y / P.scale) * PW + x / P.scale]; if (f < 0.f) f = 0.f;
+        P.out[i] = (f >= thr[n] || P.p1[i] != P.p2[i]) ? 1.f : 0.f;
     }
 }
 extern "C" int chap_diff_mask(const chap_diffmask_params* p, void* stream) {
@@ -182,7 +195,10 @@ extern "C" int chap_diff_mask(const chap_diffmask_params* p, void* stream) {
     const long total = (long)p->N * (p->H / p->scale) * (p->W / p->scale);
     hipLaunchKernelGGL(diffmask_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_diff_mask(pool)");
-    hipLaunchKernelGGL(diffmask_select_kernel, dim3(p->N), dim3(1024), 0, (hipStream_t)stream, *p);
+    float* thr = p->pooled_ws + total;          // N floats after the pooled map
+    hipLaunchKernelGGL(diffmask_select_kernel, dim3(p->N), dim3(1024), 0, (hipStream_t)stream, *p, thr);
+    const long npx = (long)p->N * p->H * p->W;
+    hipLaunchKernelGGL(diffmask_write_kernel, dim3((unsigned)((npx + 255) / 256 < 2048 ? (npx + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream, *p, (const float*)thr);
     CHAP_LAUNCH_CHECK("chap_diff_mask(select)");
     return CHAP_OK;
 }

@@ -48,11 +48,23 @@ __global__ void lcc_merge_kernel(const int64_t* lab, int* L, int N, int D, int H
     }
 }
 __global__ void lcc_count_kernel(int* L, unsigned* size, long total) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        if (L[i] < 0) continue;
-        const int r = uf_find(L, (int)i);
-        L[i] = r;                                   // path compression; roots keep L[r] == r
-        atomicAdd(&size[r], 1u);
+    // Lanes of a wave cover 64 consecutive pixels, usually of ONE component: elect a leader per distinct root
+    // and add the whole group's count with one atomic (a 500k-voxel component was 500k same-address atomics).
+    const long nwork = (total + 63) / 64 * 64;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nwork; i += (long)gridDim.x * blockDim.x) {
+        int r = -1;
+        if (i < total && L[i] >= 0) {
+            r = uf_find(L, (int)i);
+            L[i] = r;                               // path compression; roots keep L[r] == r
+        }
+        unsigned long long todo = __ballot(r >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int lr = __shfl(r, leader, 64);
+            const unsigned long long same = __ballot(r == lr) & todo;
+            if ((int)(threadIdx.x & 63) == leader) atomicAdd(&size[lr], (unsigned)__popcll(same));
+            todo &= ~same;
+        }
     }
 }
 __global__ void lcc_best_kernel(const int64_t* lab, const int* L, const unsigned* size, unsigned long long* best, int HW, int ncls, long total) {

@@ -107,6 +107,8 @@ class Executor:
             return (L.PACK_CONV_FWD, L.PACK_DOWN_DGRAD)
         if op.kind == "deconv":
             return (L.PACK_DECONV_FWD, L.PACK_DECONV_DGRAD)
+        if op.kind == "c1":
+            return (L.PACK_CONV_DGRAD,)          # dL/dx of the first layer (VAT) runs on the MFMA conv kernel: 16 -> 1 channel
         return ()
 
     def _build_pack_table(self, dtype, sd):
@@ -397,10 +399,13 @@ class Executor:
                 gt = g.raw if (g.coff == 0 and g.C == g.ld) else None
                 assert gt is not None
                 if need_dx:
-                    dx = torch.empty_like(S.x)
-                ops.conv_c1_bwd(gt, sd[op.w], S.x.view(N, D, H, W), dims=dims,
-                                dx=dx.view(N, D, H, W) if need_dx else None,
-                                dw=gr[op.w] if need_wgrad else None, db=gr[op.b] if (need_wgrad and op.b) else None)
+                    dx = torch.empty_like(S.x)      # [N, 1, *spatial] fp32 == planar output with one channel
+                    wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
+                    ops.conv_fwd([g], wp, None, 1, dx, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=dims,
+                                 out_planar=True, out_f32=True)
+                if need_wgrad:
+                    ops.conv_c1_bwd(gt, sd[op.w], S.x.view(N, D, H, W), dims=dims, dx=None,
+                                    dw=gr[op.w], db=gr[op.b] if op.b else None)
                 return
             srcs = [S.vals[s] for s in op.srcs]
             sd_, sh_, sw_ = S.dims[op.srcs[0]]

@@ -283,7 +283,8 @@ def kl_fwd_bwd(logits, targets, loss, dlogits=(None, None), gscale=1.0, gscale_d
 
 def l2_normalize(x, out, eps=1e-8):
     p = L.L2NormParams()
-    p.in_, p.out, p.N, p.P, p.eps = x.data_ptr(), out.data_ptr(), x.shape[0], x[0].numel(), eps
+    ws = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    p.in_, p.out, p.N, p.P, p.eps, p.ws = x.data_ptr(), out.data_ptr(), x.shape[0], x[0].numel(), eps, ws.data_ptr()
     L.call("chap_l2_normalize", p, _stream())
 
 
@@ -349,7 +350,7 @@ def diff_mask(p1, p2, knowledge, scale, topk):
         return diff_mask(p1.reshape(n, d * h, w), p2.reshape(n, d * h, w), knowledge.reshape(n, d * h, w), scale, topk).reshape(n, d, h, w)
     N, H, W = knowledge.shape
     out = torch.empty(N, H, W, dtype=torch.float32, device=knowledge.device)
-    ws = torch.empty(N, H // scale, W // scale, dtype=torch.float32, device=knowledge.device)
+    ws = torch.empty(N * (H // scale) * (W // scale) + N, dtype=torch.float32, device=knowledge.device)
     p = L.DiffMaskParams()
     p.p1, p.p2, p.knowledge, p.out, p.pooled_ws = p1.data_ptr(), p2.data_ptr(), knowledge.data_ptr(), out.data_ptr(), ws.data_ptr()
     p.N, p.H, p.W, p.scale, p.topk = N, H, W, scale, topk

@@ -281,7 +281,7 @@ int chap_kl_fwd_bwd(const chap_kl_params* p, void* stream);
  * DESIGN.md "P1"): per-sample L2 normalise, masked axpy / sign step, counter-based RNG.
  * `seed_dev` (optional, device uint64) is added to `seed` so a captured graph draws new numbers
  * on every replay once the host bumps that word. */
-typedef struct { const float* in; float* out; int32_t N, P; float eps; } chap_l2norm_params;
+typedef struct { const float* in; float* out; int32_t N, P; float eps; float* ws; /* N floats */ } chap_l2norm_params;
 int chap_l2_normalize(const chap_l2norm_params* p, void* stream);   /* out[n] = in[n]/(||in[n]||+eps) */
 typedef struct { const float* x; const float* d; const float* mask; float* out; float alpha; int32_t sign; int64_t n; } chap_axpy_params;
 int chap_perturb(const chap_axpy_params* p, void* stream);          /* out = x + alpha*mask*(sign? sgn(d): d) */
@@ -308,7 +308,7 @@ int    chap_largest_cc(const chap_lcc_params* p, void* stream);
 
 /* patch.create_maskV1 (ABSENT from the reference; DESIGN.md "P2"): mask = (p1 != p2) OR
  * nearest-upsample(top-k fraction of avg_pool(knowledge, scale)), per sample. out fp32 [N][H][W]. */
-typedef struct { const int64_t* p1; const int64_t* p2; const float* knowledge; float* out; float* pooled_ws;
+typedef struct { const int64_t* p1; const int64_t* p2; const float* knowledge; float* out; float* pooled_ws; /* N*(H/s)*(W/s) + N floats */
                  int32_t N, H, W, scale; float topk; } chap_diffmask_params;
 int chap_diff_mask(const chap_diffmask_params* p, void* stream);
 
