@@ -57,6 +57,7 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     // weight reuse) when the layer has plenty of pixels; small tiles when it would not fill 256 CUs.
     int NT = b.ntiles >= 4 ? 4 : (b.ntiles >= 2 ? 2 : 1);
     int MR = (geom == 2 || geom == 5) ? 1 : 2;
+    if (geom == 2 && p->dtype == CHAP_BF16 && (long)p->N * cdiv(p->D, 4) * cdiv(p->H, 4) * cdiv(p->W, 16) * cdiv(b.ntiles, NT) >= 256) MR = 4;   // z-per-wave bricks
     if (geom == 1 || geom == 3) {
         const long px = (long)p->N * p->D * p->H * p->W;
         auto blocks = [&](int mr, int nt) { return (long)p->N * p->D * cdiv(p->H, 4 * mr) * cdiv(p->W, 16) * cdiv(b.ntiles, nt); };

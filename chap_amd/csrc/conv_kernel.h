@@ -22,6 +22,12 @@
 #ifndef CHAP_ABLATE
 #define CHAP_ABLATE 0          // tools/lab/conv_lab.hip builds ablated variants; the library never does
 #endif
+#ifdef CHAP_CONV_TRACE         // lab only: per-phase s_memtime stamps of one wave per traced block
+__device__ unsigned long long chap_trace[4][64][8];
+#define CHAP_STAMP(k) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x % 257) == 0 && blockIdx.x / 257 < 4 && it < 8) chap_trace[blockIdx.x / 257][it * 4 + (threadIdx.x >> 6)][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CHAP_STAMP(k) do {} while (0)
+#endif
 
 template <int KC> struct lds_pix_stride {};        // LDS pixel stride in elements, conflict-free for
 template <> struct lds_pix_stride<32> { static constexpr int bf16 = 48, f32 = 36; };  // ds_read_b128
@@ -31,21 +37,25 @@ template <typename T, int KC> __host__ __device__ constexpr int pix_stride() {
     return sizeof(T) == 2 ? lds_pix_stride<KC>::bf16 : lds_pix_stride<KC>::f32;
 }
 
-template <int KS, int ST, bool D3, int MR> struct conv_geom {
-    static constexpr int TW = 16, TH = 4 * MR;
+// ZW ("z per wave", 3D only): the 4 waves own 4 consecutive z-planes (MR rows of 16 pixels each) instead of
+// 4*MR rows of one plane: a 4 x MR x 16 output brick has a much smaller halo per output than a slab.
+template <int KS, int ST, bool D3, int MR, bool ZW = false> struct conv_geom {
+    static constexpr int TW = 16, TH = ZW ? MR : 4 * MR, TD = ZW ? 4 : 1;
     static constexpr int KD = D3 ? KS : 1;
-    static constexpr int HW = (TW - 1) * ST + KS, HH = (TH - 1) * ST + KS, HD = KD;
+    static constexpr int STDg = D3 ? ST : 1;
+    static constexpr int HW = (TW - 1) * ST + KS, HH = (TH - 1) * ST + KS, HD = (TD - 1) * STDg + KD;
     static constexpr int HP = HD * HH * HW;
     static constexpr int NTAPS = KD * KS * KS;
     static constexpr int PAD = (KS - ST) / 2;
     static constexpr int STD = D3 ? ST : 1;
 };
 
+constexpr int HALO_DUMMY = 8;                      // elements behind each halo buffer: target of the stores of a thread's unused last unit
 constexpr int CONV_MAX_AFFINE_C = 1024;            // channels (both sources) whose scale/shift are cached in LDS
 
-template <typename T, int KS, int ST, bool D3, int KC, int MR>
+template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ZW = false>
 __host__ __device__ constexpr size_t conv_lds_fixed_bytes(int NT) {
-    return 2 * (size_t)conv_geom<KS, ST, D3, MR>::HP * pix_stride<T, KC>() * sizeof(T)   // two halo buffers
+    return 2 * ((size_t)conv_geom<KS, ST, D3, MR, ZW>::HP * pix_stride<T, KC>() + HALO_DUMMY) * sizeof(T)   // two halo buffers
            + 2 * 16 * NT * sizeof(float);                                                // block statistics
 }
 
@@ -76,6 +86,8 @@ template <> struct frag<bf16_t> {
         v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
     }
     static __device__ __forceinline__ void store(bf16_t* p, const uint4& a) { *(uint4*)p = a; }
+    static __device__ __forceinline__ uint4 pack(const float v[8]) { return make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])); }
+    static __device__ __forceinline__ uint4 select(bool keep, const uint4& a) { return make_uint4(keep ? a.x : 0u, keep ? a.y : 0u, keep ? a.z : 0u, keep ? a.w : 0u); }
 };
 template <> struct frag<float> {
     typedef f32x8 type;
@@ -85,45 +97,25 @@ template <> struct frag<float> {
         v[0] = a.lo.x; v[1] = a.lo.y; v[2] = a.lo.z; v[3] = a.lo.w; v[4] = a.hi.x; v[5] = a.hi.y; v[6] = a.hi.z; v[7] = a.hi.w;
     }
     static __device__ __forceinline__ void store(float* p, const f32x8& a) { *(float4*)p = a.lo; *(float4*)(p + 4) = a.hi; }
-};
-
-// Synchronous halo staging (used by the weight-gradient kernel): global -> transform -> LDS.
-template <typename T, int KS, int ST, bool D3, int KC, int MR>
-__device__ __forceinline__ void stage_halo(T* halo, const chap_src_t& s0, const chap_src_t& s1, int nsrc, int combine,
-                                           int n, int z0, int y0, int x0, int ID, int IH, int IW, int chunk) {
-    typedef conv_geom<KS, ST, D3, MR> G;
-    constexpr int GPT = KC / 8, PS = pix_stride<T, KC>();
-    for (int u = threadIdx.x; u < G::HP * GPT; u += 256) {
-        const int pix = u / GPT, cgl = u % GPT;
-        const int hx = pix % G::HW, hy = (pix / G::HW) % G::HH, hz = pix / (G::HW * G::HH);
-        const int gz = z0 * G::STD + hz - (D3 ? G::PAD : 0), gy = y0 * ST + hy - G::PAD, gx = x0 * ST + hx - G::PAD;
-        float v[8];
-        if ((unsigned)gz < (unsigned)ID && (unsigned)gy < (unsigned)IH && (unsigned)gx < (unsigned)IW) {
-            const long gp = (((long)n * ID + gz) * IH + gy) * IW + gx;
-            const int c = chunk * KC + cgl * 8;
-            if (combine == 0) {
-                if (c < s0.C) src_load8<T>(s0, n, gp, c, v); else src_load8<T>(s1, n, gp, c - s0.C, v);
-            } else {
-                src_load8<T>(s0, n, gp, c, v);
-                if (nsrc > 1) {
-                    float w[8];
-                    src_load8<T>(s1, n, gp, c, w);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += w[j];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        }
-        st8(halo + pix * PS + cgl * 8, v);
+    static __device__ __forceinline__ f32x8 pack(const float v[8]) { f32x8 r; r.lo = make_float4(v[0], v[1], v[2], v[3]); r.hi = make_float4(v[4], v[5], v[6], v[7]); return r; }
+    static __device__ __forceinline__ f32x8 select(bool keep, const f32x8& a) {
+        f32x8 r;
+        r.lo = make_float4(keep ? a.lo.x : 0.f, keep ? a.lo.y : 0.f, keep ? a.lo.z : 0.f, keep ? a.lo.w : 0.f);
+        r.hi = make_float4(keep ? a.hi.x : 0.f, keep ? a.hi.y : 0.f, keep ? a.hi.z : 0.f, keep ? a.hi.w : 0.f);
+        return r;
     }
-}
+};
 
 // ---- register-staged prefetch of one halo (item = tile x K-chunk) ---------------------------------
 // Everything that does not depend on the tile is computed ONCE per thread (unit -> halo coordinates,
-// LDS offset, MFMA fragment offsets, output offsets); per item only a few adds/compares remain and all
-// global addresses are (wave-uniform 64-bit base) + (32-bit lane offset).
+// LDS offset); per item a unit costs a handful of VALU instructions:
+//   * bounds: the halo coordinates are packed (hz<<20 | hy<<10 | hx, 9 bits + 1 guard bit each); adding the
+//     packed (512 - lo) and (512 - hi) of the wave-uniform valid range sets the guard bit of a field iff
+//     f >= lo resp. f >= hi, so "inside" is ((d+PA) ^ (d+PB)) & GUARD == GUARD;
+//   * address: wave-uniform 64-bit base (SGPR pair) + 32-bit lane offset -> global_load saddr form;
+//   * NO branch around a load: out-of-range units read the tile's first output pixel (always inside the
+//     input) and are zeroed at commit time.  A load inside a divergent `if` makes the compiler put an
+//     s_waitcnt vmcnt(0) in front of every one of them, which serialises the whole prefetch.
 template <typename T, int UNITS, bool ADD2> struct halo_regs {
     typename frag<T>::type raw[UNITS];
     typename frag<T>::type raw2[ADD2 ? UNITS : 1];
@@ -131,12 +123,32 @@ template <typename T, int UNITS, bool ADD2> struct halo_regs {
     unsigned ok;               // bit j: unit j is inside the input (else zero padding)
 };
 
+constexpr int UNIT_UNUSED = 511 << 20;                          // z field beyond any halo: never inside
+constexpr unsigned UNIT_GUARD = (1u << 29) | (1u << 19) | (1u << 9);
+
 template <int UNITS> struct unit_desc {
-    int hzyx[UNITS];           // hz << 20 | hy << 10 | hx   (-1: unit not used by this thread)
+    int hzyx[UNITS];           // hz << 20 | hy << 10 | hx   (UNIT_UNUSED: this thread has no such unit; only the last can be)
     int rel[UNITS];            // (hz*IH + hy)*IW + hx : input pixel offset from the halo origin
     int lds[UNITS];            // pix*PS + cgl*8 (elements)
-    int c8[UNITS];             // cgl*8
+    int c8;                    // first of this thread's 8 channels inside a K-chunk (256 % GPT == 0: same for all its units)
 };
+
+template <typename G, int GPT, int PS, int UNITS>
+__device__ __forceinline__ void make_units(unit_desc<UNITS>& U, int IH, int IW) {
+    U.c8 = (threadIdx.x % GPT) * 8;
+#pragma unroll
+    for (int j = 0; j < UNITS; ++j) {
+        const int u = threadIdx.x + 256 * j;
+        U.hzyx[j] = UNIT_UNUSED; U.rel[j] = 0; U.lds[j] = G::HP * PS;    // dummy slot: every unit is staged and stored unconditionally
+        if (u < G::HP * GPT) {
+            const int pix = u / GPT, cgl = u % GPT;
+            const int hx = pix % G::HW, hy = (pix / G::HW) % G::HH, hz = pix / (G::HW * G::HH);
+            U.hzyx[j] = (hz << 20) | (hy << 10) | hx;
+            U.rel[j] = (hz * IH + hy) * IW + hx;
+            U.lds[j] = pix * PS + cgl * 8;
+        }
+    }
+}
 
 struct src_scalars {           // wave-uniform per-source values hoisted out of the loops
     const void* ptr; const uint8_t* keep; const float* chan_mul;
@@ -149,141 +161,221 @@ __device__ __forceinline__ src_scalars make_scalars(const chap_src_t& s) {
     return r;
 }
 
-template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int UNITS>
-__device__ __forceinline__ void halo_issue(halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, const src_scalars& s0, const src_scalars& s1,
-                                           int ID, int IH, int IW, int n, int z0, int y0, int x0, int chunk) {
-    typedef conv_geom<KS, ST, D3, MR> G;
+// LANESEL: the K-chunk straddles the two concatenated sources (s0.C % KC != 0), so the source is a per-thread
+// choice (64-bit lane addresses); otherwise it is wave-uniform per item and everything below stays scalar.
+template <typename T, typename G, bool D3, int ST, int KC, bool ADD2, int UNITS, bool LANESEL>
+__device__ __forceinline__ void halo_issue_impl(halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, const src_scalars& s0, const src_scalars& s1,
+                                                int ID, int IH, int IW, int n, int z0, int y0, int x0, int chunk) {
     const int gz0 = z0 * G::STD - (D3 ? G::PAD : 0), gy0 = y0 * ST - G::PAD, gx0 = x0 * ST - G::PAD;
     const long gp0 = (((long)n * ID + gz0) * IH + gy0) * IW + gx0;           // halo origin (may lie outside: only offsets that pass the bounds test are used)
-    const T* b0 = (const T*)s0.ptr + gp0 * s0.ld + s0.coff;
-    const T* b1 = (const T*)s1.ptr + gp0 * s1.ld + s1.coff;
-    const uint8_t* k0 = s0.keep + gp0 * s0.C;
-    const uint8_t* k1 = s1.keep + gp0 * s1.C;
-    const int cbase = chunk * KC;
-    R.ok = 0;
+    const int loz = max(0, -gz0), hiz = min(G::HD, ID - gz0), loy = max(0, -gy0), hiy = min(G::HH, IH - gy0), lox = max(0, -gx0), hix = min(G::HW, IW - gx0);
+    const unsigned PA = ((unsigned)(512 - loz) << 20) | ((unsigned)(512 - loy) << 10) | (unsigned)(512 - lox);
+    const unsigned PB = ((unsigned)(512 - hiz) << 20) | ((unsigned)(512 - hiy) << 10) | (unsigned)(512 - hix);
+    const unsigned rsafe = ((D3 ? G::PAD : 0) * IH + G::PAD) * IW + G::PAD;
+    const int cb = chunk * KC;
+    const bool second = ADD2 ? false : (LANESEL ? (cb + U.c8 >= s0.C) : (cb >= s0.C));
+    const int cs = second ? cb - s0.C : cb;                      // first channel of the chunk inside the source (can be < 0 for LANESEL lanes of s1: + c8 >= 0)
+    const int ld = second ? s1.ld : s0.ld;
+    const char* base = (const char*)(second ? s1.ptr : s0.ptr) + (gp0 * ld + (second ? s1.coff : s0.coff) + cs) * (long)sizeof(T);
+    const unsigned ldb = ld * sizeof(T), lane_c = U.c8 * sizeof(T);
+    unsigned okm = 0, r[UNITS];
 #pragma unroll
     for (int j = 0; j < UNITS; ++j) {
-        const int d = U.hzyx[j];
-        if (CHAP_ABLATE & 16) continue;
-        const int hz = d >> 20, hy = (d >> 10) & 1023, hx = d & 1023;
-        const bool ok = d >= 0 && (unsigned)(gz0 + hz) < (unsigned)ID && (unsigned)(gy0 + hy) < (unsigned)IH && (unsigned)(gx0 + hx) < (unsigned)IW;
-        if (ok) {
-            R.ok |= 1u << j;
-            int c = cbase + U.c8[j];
-            if (ADD2) {
-                R.raw[j] = frag<T>::load(b0 + U.rel[j] * s0.ld + c);
-                R.raw2[j] = frag<T>::load(b1 + U.rel[j] * s1.ld + c);
-                if (s0.has_keep) R.keep[j] = *(const uint2*)(k0 + U.rel[j] * s0.C + c);
-            } else {
-                const bool second = c >= s0.C;
-                c = second ? c - s0.C : c;
-                const T* b = second ? b1 : b0;
-                const int ld = second ? s1.ld : s0.ld;
-                R.raw[j] = frag<T>::load(b + U.rel[j] * ld + c);
-                const bool hk = second ? s1.has_keep : s0.has_keep;
-                if (hk) {
-                    const uint8_t* kb = second ? k1 : k0;
-                    const int kc = second ? s1.C : s0.C;
-                    R.keep[j] = *(const uint2*)(kb + U.rel[j] * kc + c);
-                }
-            }
+        const unsigned d = (unsigned)U.hzyx[j];
+        const bool ok = (((d + PA) ^ (d + PB)) & UNIT_GUARD) == UNIT_GUARD;
+        okm |= ok ? (1u << j) : 0u;
+        r[j] = ok ? (unsigned)U.rel[j] : rsafe;
+    }
+    R.ok = okm;
+    if (CHAP_ABLATE & 16) return;
+#pragma unroll
+    for (int j = 0; j < UNITS; ++j) R.raw[j] = frag<T>::load((const T*)(base + (__umul24(r[j], ldb) + lane_c)));
+    if (ADD2) {
+        const char* base2 = (const char*)s1.ptr + (gp0 * s1.ld + s1.coff + cb) * (long)sizeof(T);
+        const unsigned ldb2 = s1.ld * sizeof(T);
+#pragma unroll
+        for (int j = 0; j < UNITS; ++j) R.raw2[j] = frag<T>::load((const T*)(base2 + (__umul24(r[j], ldb2) + lane_c)));
+    }
+    // element keep masks (Dropout): u8 [pixel][C] of the source.  The registers are (re)defined on BOTH paths: a
+    // value carried over from the previous item would come back as register copies behind the loads, each with
+    // its own s_waitcnt -- i.e. a synchronous prefetch.
+    const bool hk = second ? s1.has_keep : s0.has_keep;
+    if (!(LANESEL ? (s0.has_keep || s1.has_keep) : hk)) {
+#pragma unroll
+        for (int j = 0; j < UNITS; ++j) R.keep[j] = make_uint2(0u, 0u);
+    } else {                                                     // wave-uniform
+        const int kC = second ? s1.C : s0.C;
+        const uint8_t* kb = (second ? s1.keep : s0.keep) + (gp0 * kC + cs);
+#pragma unroll
+        for (int j = 0; j < UNITS; ++j) {
+            const uint8_t* kp = kb + (__umul24(r[j], (unsigned)kC) + (unsigned)U.c8);
+            // LANESEL lanes whose source has no mask read 8 bytes of their own data instead (ignored at commit)
+            if (LANESEL) kp = hk ? kp : (const uint8_t*)(base + (__umul24(r[j], ldb) + lane_c));
+            R.keep[j] = *(const uint2*)kp;
         }
     }
+}
+
+template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int UNITS, bool ZW = false>
+__device__ __forceinline__ void halo_issue(halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, const src_scalars& s0, const src_scalars& s1,
+                                           int ID, int IH, int IW, int n, int z0, int y0, int x0, int chunk, bool lanesel) {
+    typedef conv_geom<KS, ST, D3, MR, ZW> G;
+    if (!ADD2 && lanesel) halo_issue_impl<T, G, D3, ST, KC, ADD2, UNITS, true>(R, U, s0, s1, ID, IH, IW, n, z0, y0, x0, chunk);
+    else halo_issue_impl<T, G, D3, ST, KC, ADD2, UNITS, false>(R, U, s0, s1, ID, IH, IW, n, z0, y0, x0, chunk);
 }
 
 // affine cache layout in LDS: [src][scale | shift][CONV_MAX_AFFINE_C/2] (identity when a source has none).
 // Packed fp32 math (v_pk_fma_f32 / v_pk_mul_f32, 2 elements per VALU instruction): the commit phase is
 // VALU-issue-bound.  leaky(z) = max(z, slope*z) for 0 <= slope <= 1 (slope_eff = 1: no activation).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// scale/shift of the 8 channels a thread stages, held in registers (per K-chunk; they do not depend on the tile)
+template <bool ADD2> struct aff_regs { f32x2 a[4], b[4], a2[ADD2 ? 4 : 1], b2[ADD2 ? 4 : 1]; };
+
+template <int KC, bool ADD2>
+__device__ __forceinline__ void load_aff(aff_regs<ADD2>& A, const float* aff, int c8, int C0, int chunk, bool lanesel) {
+    const int cb = chunk * KC;
+    const bool second = ADD2 ? false : (lanesel ? (cb + c8 >= C0) : (cb >= C0));
+    const float* af = aff + (second ? CONV_MAX_AFFINE_C + cb - C0 : cb) + c8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { A.a[k] = *(const f32x2*)(af + 2 * k); A.b[k] = *(const f32x2*)(af + CONV_MAX_AFFINE_C / 2 + 2 * k); }
+    if (ADD2) {
+        const float* af2 = aff + CONV_MAX_AFFINE_C + cb + c8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { A.a2[k] = *(const f32x2*)(af2 + 2 * k); A.b2[k] = *(const f32x2*)(af2 + CONV_MAX_AFFINE_C / 2 + 2 * k); }
+    }
+}
+
+// v <- leaky(v * a + b) with slope_eff folded as max(z, slope*z)
+__device__ __forceinline__ void affine_act8(float v[8], const f32x2 a[4], const f32x2 b[4], float slope_eff) {
+    const f32x2 sl = {slope_eff, slope_eff};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f32x2 z = {v[2 * k], v[2 * k + 1]};
+        z = z * a[k] + b[k];
+        const f32x2 m = z * sl;
+        v[2 * k] = fmaxf(z.x, m.x); v[2 * k + 1] = fmaxf(z.y, m.y);
+    }
+}
+__device__ __forceinline__ void keep8(float v[8], uint2 keep, float keep_scale) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t w = j < 4 ? keep.x : keep.y;
+        v[j] = ((w >> (8 * (j & 3))) & 0xff) ? v[j] * keep_scale : 0.f;
+    }
+}
+
+// one-shot variant (reads scale/shift from the LDS cache) for operands staged once per tile
 __device__ __forceinline__ void lazy_transform(float v[8], const float* aff, int c, float slope_eff, bool has_keep, uint2 keep, float keep_scale,
                                                const float* cm) {
-    const f32x2 sl = {slope_eff, slope_eff};
-    const f32x2* a2 = (const f32x2*)(aff + c);
-    const f32x2* b2 = (const f32x2*)(aff + CONV_MAX_AFFINE_C / 2 + c);
+    f32x2 a[4], b[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        f32x2 z = {v[2 * j], v[2 * j + 1]};
-        z = z * a2[j] + b2[j];
-        const f32x2 m = z * sl;
-        v[2 * j] = fmaxf(z.x, m.x); v[2 * j + 1] = fmaxf(z.y, m.y);
-    }
-    if (has_keep) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t w = j < 4 ? keep.x : keep.y;
-            v[j] = ((w >> (8 * (j & 3))) & 0xff) ? v[j] * keep_scale : 0.f;
-        }
-    }
+    for (int k = 0; k < 4; ++k) { a[k] = *(const f32x2*)(aff + c + 2 * k); b[k] = *(const f32x2*)(aff + CONV_MAX_AFFINE_C / 2 + c + 2 * k); }
+    affine_act8(v, a, b, slope_eff);
+    if (has_keep) keep8(v, keep, keep_scale);
     if (cm) {
-        float a[8];
-        ld8(cm + c, a);
+        float m[8];
+        ld8(cm + c, m);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= a[j];
+        for (int j = 0; j < 8; ++j) v[j] *= m[j];
     }
 }
 
-template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int UNITS>
-__device__ __forceinline__ void halo_commit(const halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
-                                            const float* aff, bool plain, int n, int chunk) {
-    const int cbase = chunk * KC;
+template <typename T, int KC, bool ADD2, int UNITS, bool LANESEL>
+__device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
+                                                 const float* aff, bool plain, int n, int chunk) {
+    typedef typename frag<T>::type F;
+    // no per-unit branches: a path that skips a unit would leave its prefetch load un-waited as far as the compiler
+    // can tell, and the next item's issue phase would then wait for every outstanding memory operation
+    if (plain) {
+#pragma unroll
+        for (int j = 0; j < UNITS; ++j) frag<T>::store(halo + U.lds[j], frag<T>::select((R.ok >> j) & 1u, R.raw[j]));
+        return;
+    }
+    const int cb = chunk * KC;
+    const bool second = ADD2 ? false : (LANESEL ? (cb + U.c8 >= s0.C) : (cb >= s0.C));
+    const float se = second ? s1.slope_eff : s0.slope_eff;
+    const bool hk = second ? s1.has_keep : s0.has_keep;
+    const float ks = second ? s1.keep_scale : s0.keep_scale;
+    const bool hcm = second ? s1.has_cm : s0.has_cm;
+    // scale/shift of this thread's 8 channels: 4 LDS reads per item are cheaper than 16 registers held across the MFMA loop
+    aff_regs<ADD2> A;
+    load_aff<KC, ADD2>(A, aff, U.c8, s0.C, chunk, LANESEL);
+    f32x2 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[k] = A.a[k]; b[k] = A.b[k]; }
+    // per-sample channel multipliers (Dropout3d / channel masks; rare, so loaded here rather than carried in registers).
+    // They are >= 0: cm * leaky(a x + b) = leaky((cm a) x + cm b)
+    if (LANESEL ? (s0.has_cm || s1.has_cm) : hcm) {
+        const int cs = (second ? cb - s0.C : cb) + U.c8;
+        const float* cp = second ? s1.chan_mul + (long)n * s1.C + cs : s0.chan_mul + (long)n * s0.C + cs;
+        if (LANESEL) cp = hcm ? cp : (s0.has_cm ? s0.chan_mul : s1.chan_mul);
+        float cm[8];
+        ld8(cp, cm);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x2 m = {cm[2 * k], cm[2 * k + 1]};
+            if (LANESEL) { m.x = hcm ? m.x : 1.f; m.y = hcm ? m.y : 1.f; }
+            a[k] *= m; b[k] *= m;
+        }
+    }
+    const bool anyk = LANESEL ? (s0.has_keep || s1.has_keep) : hk;
 #pragma unroll
     for (int j = 0; j < UNITS; ++j) {
-        if (U.hzyx[j] < 0) continue;
-        T* dst = halo + U.lds[j];
-        if (!((R.ok >> j) & 1u)) { frag<T>::store(dst, frag<T>::zero()); continue; }
-        if (plain) { frag<T>::store(dst, R.raw[j]); continue; }
         float v[8];
         frag<T>::unpack(R.raw[j], v);
-        int c = cbase + U.c8[j];
+        affine_act8(v, a, b, se);
+        if (anyk) {
+            uint2 kp = R.keep[j];
+            if (LANESEL) { kp.x = hk ? kp.x : 0x01010101u; kp.y = hk ? kp.y : 0x01010101u; }
+            keep8(v, kp, (LANESEL && !hk) ? 1.f : ks);
+        }
         if (ADD2) {
-            lazy_transform(v, aff, c, s0.slope_eff, s0.has_keep, R.keep[j], s0.keep_scale, s0.has_cm ? s0.chan_mul + (long)n * s0.C : nullptr);
             float w[8];
             frag<T>::unpack(R.raw2[j], w);
-            lazy_transform(w, aff + CONV_MAX_AFFINE_C, c, s1.slope_eff, false, make_uint2(0, 0), 1.f, s1.has_cm ? s1.chan_mul + (long)n * s1.C : nullptr);
+            affine_act8(w, A.a2, A.b2, s1.slope_eff);
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] += w[k];
-        } else {
-            const bool second = c >= s0.C;
-            c = second ? c - s0.C : c;
-            const float* af = second ? aff + CONV_MAX_AFFINE_C : aff;
-            const float se = second ? s1.slope_eff : s0.slope_eff;
-            const bool hk = second ? s1.has_keep : s0.has_keep;
-            const float ks = second ? s1.keep_scale : s0.keep_scale;
-            const float* cm = second ? (s1.has_cm ? s1.chan_mul + (long)n * s1.C : nullptr) : (s0.has_cm ? s0.chan_mul + (long)n * s0.C : nullptr);
-            lazy_transform(v, af, c, se, hk, R.keep[j], ks, cm);
         }
-        st8(dst, v);
+        frag<T>::store(halo + U.lds[j], frag<T>::select((R.ok >> j) & 1u, frag<T>::pack(v)));
     }
 }
 
-// tile index -> (n, z0, y0, x0)
-template <int TH, int TW>
-__device__ __forceinline__ void tile_coords(long tile, int tiles_x, int tiles_y, int D, int& n, int& z0, int& y0, int& x0) {
+template <typename T, int KC, bool ADD2, int UNITS>
+__device__ __forceinline__ void halo_commit(const halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
+                                            const float* aff, bool plain, int n, int chunk, bool lanesel) {
+    if (!ADD2 && lanesel) halo_commit_impl<T, KC, ADD2, UNITS, true>(R, U, halo, s0, s1, aff, plain, n, chunk);
+    else halo_commit_impl<T, KC, ADD2, UNITS, false>(R, U, halo, s0, s1, aff, plain, n, chunk);
+}
+
+// tile index -> (n, z0, y0, x0); tiles_z = number of tile layers along D (D itself when the tile is one plane)
+template <int TH, int TW, int TD = 1>
+__device__ __forceinline__ void tile_coords(long tile, int tiles_x, int tiles_y, int tiles_z, int& n, int& z0, int& y0, int& x0) {
     const unsigned t = (unsigned)tile;
     const unsigned tx = t % (unsigned)tiles_x; unsigned r = t / (unsigned)tiles_x;
     const unsigned ty = r % (unsigned)tiles_y; r /= (unsigned)tiles_y;
-    z0 = (int)(r % (unsigned)D); n = (int)(r / (unsigned)D);
+    z0 = (int)(r % (unsigned)tiles_z) * TD; n = (int)(r / (unsigned)tiles_z);
     x0 = (int)tx * TW; y0 = (int)ty * TH;
 }
 
-template <typename T, int KS, int ST, bool D3, int KC, int NT, int MR, bool ADD2, bool WLDS>
+template <typename T, int KS, int ST, bool D3, int KC, int NT, int MR, bool ADD2, bool WLDS, bool ZW = false>
 __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES : (KC == 16 && !D3 ? 4 : 1))) void conv_fwd_kernel(const chap_conv_params P) {
-    typedef conv_geom<KS, ST, D3, MR> G;
+    typedef conv_geom<KS, ST, D3, MR, ZW> G;
     typedef typename frag<T>::type F;
     constexpr int GPT = KC / 8, PS = pix_stride<T, KC>();
     constexpr int NP = G::NTAPS * GPT, STEPS = (NP + 3) / 4;
     constexpr int UNITS = (G::HP * GPT + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* halo0 = (T*)smem;
-    T* halo1 = halo0 + (size_t)G::HP * PS;
-    float* bstat = (float*)(halo1 + (size_t)G::HP * PS);
+    T* halo1 = halo0 + (size_t)G::HP * PS + HALO_DUMMY;
+    float* bstat = (float*)(halo1 + (size_t)G::HP * PS + HALO_DUMMY);
     float* aff = bstat + 2 * 16 * NT;                       // [2 sources][scale | shift][CONV_MAX_AFFINE_C/2]
     T* wlds = (T*)(aff + 2 * CONV_MAX_AFFINE_C);            // WLDS only
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
-    const int tiles_x = (P.W + G::TW - 1) / G::TW, tiles_y = (P.H + G::TH - 1) / G::TH;
-    const long ntiles = (long)P.N * P.D * tiles_y * tiles_x;
+    const int tiles_x = (P.W + G::TW - 1) / G::TW, tiles_y = (P.H + G::TH - 1) / G::TH, tiles_z = (P.D + G::TD - 1) / G::TD;
+    const long ntiles = (long)P.N * tiles_z * tiles_y * tiles_x;
     const int ntiles_total = (P.Cout + 15) >> 4;
     const int nt0 = blockIdx.y * NT;
     const int Ctot = P.combine == 0 ? (P.src[0].C + (P.nsrc > 1 ? P.src[1].C : 0)) : P.src[0].C;
@@ -306,61 +398,70 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
 
     // ---- one-time per thread: unit descriptors, MFMA fragment offsets ----
     unit_desc<UNITS> U;
-#pragma unroll
-    for (int j = 0; j < UNITS; ++j) {
-        const int u = threadIdx.x + 256 * j;
-        U.hzyx[j] = -1; U.rel[j] = 0; U.lds[j] = 0; U.c8[j] = 0;
-        if (u < G::HP * GPT) {
-            const int pix = u / GPT, cgl = u % GPT;
-            const int hx = pix % G::HW, hy = (pix / G::HW) % G::HH, hz = pix / (G::HW * G::HH);
-            U.hzyx[j] = (hz << 20) | (hy << 10) | hx;
-            U.rel[j] = (hz * P.IH + hy) * P.IW + hx;
-            U.lds[j] = pix * PS + cgl * 8;
-            U.c8[j] = cgl * 8;
-        }
-    }
+    make_units<G, GPT, PS, UNITS>(U, P.IH, P.IW);
+    const bool lanesel = !ADD2 && P.nsrc > 1 && (P.src[0].C % KC) != 0;   // a K-chunk straddles the two concatenated sources
     int xoff[STEPS];                                            // LDS element offset of this lane's B fragment (row m = 0), -1 = zero fragment
 #pragma unroll
     for (int step = 0; step < STEPS; ++step) {
         const int p = step * 4 + g;
         const int tap = p / GPT, cgl = p % GPT;
         const int dx = tap % KS, dy = (tap / KS) % KS, dz = tap / (KS * KS);
-        xoff[step] = p < NP ? ((dz * G::HH + (wave * MR) * ST + dy) * G::HW + px * ST + dx) * PS + cgl * 8 : -1;
+        xoff[step] = p < NP ? (ZW ? (((dz + wave * G::STDg) * G::HH + dy) * G::HW + px * ST + dx) * PS + cgl * 8
+                                  : ((dz * G::HH + (wave * MR) * ST + dy) * G::HW + px * ST + dx) * PS + cgl * 8) : -1;
     }
 
-    // ---- one-time per block: affine cache, resident weights ----
+    // ---- one-time per block.  Every global load of the prologue (first halo, scale/shift, resident weights,
+    // bias) is issued before the first dependent LDS store, so that the block pays ONE memory round trip before
+    // its first tile instead of four in a row (a block only owns a handful of tiles: this is a large part of
+    // its life).  No load sits inside a divergent branch (see halo_issue).
+    halo_regs<T, UNITS, ADD2> R;
+    // tile walk: this block visits tiles t_begin + bix + k*bpx; the (x, y, z, n) tile coordinates advance by the
+    // mixed-radix digits of bpx with carries (scalar adds/compares instead of three divisions per tile)
+    int ntx = 0, nty = 0, ntz = 0, nn = 0;                      // tile coordinates of the item being prefetched
+    int sx, sy, sz, sn;
+    {
+        unsigned r = (unsigned)bpx;
+        sx = r % (unsigned)tiles_x; r /= (unsigned)tiles_x;
+        sy = r % (unsigned)tiles_y; r /= (unsigned)tiles_y;
+        sz = r % (unsigned)tiles_z; sn = r / (unsigned)tiles_z;
+        unsigned t = (unsigned)(t_begin + bix);
+        ntx = t % (unsigned)tiles_x; t /= (unsigned)tiles_x;
+        nty = t % (unsigned)tiles_y; t /= (unsigned)tiles_y;
+        ntz = t % (unsigned)tiles_z; nn = t / (unsigned)tiles_z;
+    }
+    if (nitems > 0)
+        halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, ntz * G::TD, nty * G::TH, ntx * G::TW, 0, lanesel);
+
+    // scale/shift of both sources -> registers (CONV_MAX_AFFINE_C/2 = 512 channels per source: 2 per thread)
+    float asc[2][2], ash[2][2];
     if (!plain) {
-        for (int s = 0; s < P.nsrc; ++s) {
-            const bool has = P.src[s].scale != nullptr;
-            for (int c = threadIdx.x; c < P.src[s].C; c += 256) {
-                aff[s * CONV_MAX_AFFINE_C + c] = has ? P.src[s].scale[c] : 1.f;
-                aff[s * CONV_MAX_AFFINE_C + CONV_MAX_AFFINE_C / 2 + c] = has ? P.src[s].shift[c] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const chap_src_t& S = P.src[s < P.nsrc ? s : 0];
+            const bool has = S.scale != nullptr;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = min((int)threadIdx.x + 256 * k, S.C - 1);
+                asc[s][k] = 1.f; ash[s][k] = 0.f;
+                if (has) { asc[s][k] = S.scale[c]; ash[s][k] = S.shift[c]; }      // wave-uniform branch
             }
         }
     }
     const long wstep = (long)ntiles_total * 64 * 8;             // packed elements per (chunk, step)
+    // resident weights: [chunk][step][t < NT][64 lanes][8]; first batch of 8 fragments per thread in flight now
+    const long wtot = WLDS ? (long)nchunks * STEPS * NT * 64 : 0;
+    auto wload = [&](long i) -> F {
+        const long ic = i < wtot ? i : 0;                        // clamp, no branch around the load
+        const int ln = (int)(ic & 63); long r = ic >> 6;
+        int t = (int)(r % NT); r /= NT;                          // r = chunk*STEPS + step
+        t = nt0 + t < ntiles_total ? t : 0;
+        return frag<T>::load((const T*)P.wpacked + r * wstep + ((long)(nt0 + t) * 64 + ln) * 8);
+    };
+    auto wkeep = [&](long i) -> bool { return i < wtot && nt0 + (int)((i >> 6) % NT) < ntiles_total; };
+    F wf0[8];
     if (WLDS) {
-        // resident copy: [chunk][step][t < NT][64 lanes][8]; 8 loads in flight per thread (a load->store->load
-        // chain would serialise ~1 us of L2 latency per 16 bytes)
-        const long tot = (long)nchunks * STEPS * NT * 64;
-        for (long i0 = threadIdx.x; i0 < tot; i0 += 256 * 8) {
-            F f[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const long i = i0 + 256 * k;
-                f[k] = frag<T>::zero();
-                if (i < tot) {
-                    const int ln = (int)(i & 63); long r = i >> 6;
-                    const int t = (int)(r % NT); r /= NT;            // r = chunk*STEPS + step
-                    if (nt0 + t < ntiles_total) f[k] = frag<T>::load((const T*)P.wpacked + r * wstep + ((long)(nt0 + t) * 64 + ln) * 8);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const long i = i0 + 256 * k;
-                if (i < tot) frag<T>::store(wlds + i * 8, f[k]);
-            }
-        }
+        for (int k = 0; k < 8; ++k) wf0[k] = wload((long)threadIdx.x + 256 * k);
     }
 
     f32x4 acc[MR][NT];
@@ -371,14 +472,51 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         const int cb = P.out_mode == 1 ? (nl % P.out_Cn) : nl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            ssum[t][j] = 0.f; ssq[t][j] = 0.f;
-            bj[t][j] = (P.bias && nl + j < P.Cout) ? P.bias[cb + j] : 0.f;
+            ssum[t][j] = 0.f; ssq[t][j] = 0.f; bj[t][j] = 0.f;
+            if (P.bias) {                                        // wave-uniform; index clamped instead of a lane branch
+                const float b = P.bias[nl + j < P.Cout ? cb + j : 0];
+                bj[t][j] = nl + j < P.Cout ? b : 0.f;
+            }
         }
     }
+    // ---- now the dependent LDS stores
+    if (!plain) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if (s < P.nsrc) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int c = threadIdx.x + 256 * k;
+                    if (c < P.src[s].C) { aff[s * CONV_MAX_AFFINE_C + c] = asc[s][k]; aff[s * CONV_MAX_AFFINE_C + CONV_MAX_AFFINE_C / 2 + c] = ash[s][k]; }
+                }
+            }
+        }
+    }
+    if (WLDS) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const long i = (long)threadIdx.x + 256 * k;
+            if (i < wtot) frag<T>::store(wlds + i * 8, wkeep(i) ? wf0[k] : frag<T>::zero());
+        }
+        for (long i0 = (long)threadIdx.x + 256 * 8; i0 < wtot; i0 += 256 * 8) {     // larger layers: further batches of 8
+            F f[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = wload(i0 + 256 * k);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const long i = i0 + 256 * k;
+                if (i < wtot) frag<T>::store(wlds + i * 8, wkeep(i) ? f[k] : frag<T>::zero());
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bj[t][j]));   // land the bias loads here, not behind the first prefetch of the item loop
     const bool do_stats = P.stats != nullptr;
     const int SD2 = (P.dims == 3) ? 2 : 1;
     // per-lane output offsets relative to the tile origin (elements), one per (t): row term added per m
-    int ooff[NT], orow;                                         // orow = element stride of one tile row
+    int ooff[NT], orow, oplane;                                 // orow / oplane = element stride of one tile row / z-plane
     {
         const int OW = P.out_mode == 1 ? 2 * P.W : P.W, OH = P.out_mode == 1 ? 2 * P.H : P.H;
 #pragma unroll
@@ -395,26 +533,21 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
             }
         }
         orow = P.out_planar ? P.W : (P.out_mode == 1 ? 2 * OW * P.out_ld : P.W * P.out_ld);
+        oplane = P.out_planar ? P.H * P.W : (P.out_mode == 1 ? 2 * OH * OW * P.out_ld : P.H * P.W * P.out_ld);   // one z-plane (ZW tiles)
     }
 
-    halo_regs<T, UNITS, ADD2> R;
     int n = 0, z0 = 0, y0 = 0, x0 = 0;
-    int nn = 0, nz0 = 0, ny0 = 0, nx0 = 0;                      // coordinates of the item being prefetched
-    if (nitems > 0) {
-        tile_coords<G::TH, G::TW>(t_begin + bix, tiles_x, tiles_y, P.D, nn, nz0, ny0, nx0);
-        halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, nz0, ny0, nx0, 0);
-    }
     __syncthreads();                                            // affine cache (+ resident weights) visible
-    if (nitems > 0) halo_commit<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, halo0, s0, s1, aff, plain, nn, 0);
+    if (nitems > 0) halo_commit<T, KC, ADD2, UNITS>(R, U, halo0, s0, s1, aff, plain, nn, 0, lanesel);
     __syncthreads();
 
-    long tile_k = 0;                                            // index into this block's tile list
     int chunk = 0;
     for (long it = 0; it < nitems; ++it) {
         T* cur = (it & 1) ? halo1 : halo0;
         T* nxt = (it & 1) ? halo0 : halo1;
+        CHAP_STAMP(0);
         if (chunk == 0) {
-            n = nn; z0 = nz0; y0 = ny0; x0 = nx0;
+            n = nn; z0 = ntz * G::TD; y0 = nty * G::TH; x0 = ntx * G::TW;
 #pragma unroll
             for (int m = 0; m < MR; ++m)
 #pragma unroll
@@ -426,10 +559,14 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         if (has_next) {
             if (nchunk == nchunks) {
                 nchunk = 0;
-                tile_coords<G::TH, G::TW>(t_begin + bix + (tile_k + 1) * bpx, tiles_x, tiles_y, P.D, nn, nz0, ny0, nx0);
+                ntx += sx; int c = ntx >= tiles_x; ntx -= c ? tiles_x : 0;
+                nty += sy + c; c = nty >= tiles_y; nty -= c ? tiles_y : 0;
+                ntz += sz + c; c = ntz >= tiles_z; ntz -= c ? tiles_z : 0;
+                nn += sn + c;
             }
-            halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, nz0, ny0, nx0, nchunk);
+            halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, ntz * G::TD, nty * G::TH, ntx * G::TW, nchunk, lanesel);
         }
+        CHAP_STAMP(1);
         // ---- MFMA over the taps of this chunk
         const T* wc_g = (const T*)P.wpacked + (long)chunk * STEPS * wstep + ((long)nt0 * 64 + lane) * 8;
         const T* wc_l = wlds + ((long)chunk * STEPS * NT * 64 + lane) * 8;
@@ -444,13 +581,16 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
             const int xo = xoff[step];
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                F xf = xo >= 0 ? frag<T>::load(cur + xo + m * (ST * G::HW * PS)) : frag<T>::zero();
+                F xf;
+                if (step * 4 + 3 < NP) xf = frag<T>::load(cur + xo + m * (ST * G::HW * PS));        // every lane group has a tap
+                else xf = xo >= 0 ? frag<T>::load(cur + xo + m * (ST * G::HW * PS)) : frag<T>::zero();
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     if (CHAP_ABLATE & 1) { float kx[8], kw[8]; frag<T>::unpack(xf, kx); frag<T>::unpack(wf[t], kw); asm volatile("" :: "v"(kx[0]), "v"(kx[7]), "v"(kw[0]), "v"(kw[7])); } else mma8(acc[m][t], wf[t], xf);
                 }
             }
         }
+        CHAP_STAMP(2);
         // ---- epilogue after the last K-chunk of a tile: lane holds D[cout = 16*t + 4*g + j][pixel (row m, x = px)]
         if (chunk == nchunks - 1) {
             const bool xok = x0 + px < P.W;
@@ -459,46 +599,70 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
             if (P.out_planar) o0 = ((long)n * P.Cout * P.D + z0) * P.H * P.W + (long)y0 * P.W + x0;     // + c*plane
             else if (P.out_mode == 1) o0 = ((((long)n * (P.D * SD2) + z0 * SD2) * (2 * P.H) + 2 * y0) * (2 * P.W) + 2 * x0) * P.out_ld;
             else o0 = ((((long)n * P.D + z0) * P.H + y0) * P.W + x0) * P.out_ld;
-            const long plane = (long)P.D * P.H * P.W;
+            const int zw_off = ZW ? wave * oplane : 0;
+            const bool zok = !ZW || z0 + wave < P.D;
+            if (P.out_planar || (P.Cout & 3)) {
+                // heads (planar fp32 logits) and odd channel counts: element stores
+                const long plane = (long)P.D * P.H * P.W;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int nl = (nt0 + t) * 16 + 4 * g;            // logical output channel of j = 0
-                if (nl >= P.Cout) continue;
+                for (int t = 0; t < NT; ++t) {
+                    const int nl = (nt0 + t) * 16 + 4 * g;        // logical output channel of j = 0
 #pragma unroll
-                for (int m = 0; m < MR; ++m) {
-                    const int row = wave * MR + m;
-                    const bool valid = xok && (y0 + row < P.H);
-                    float v[4];
+                    for (int m = 0; m < MR; ++m) {
+                        const int row = ZW ? m : wave * MR + m;
+                        const bool valid = xok && zok && (y0 + row < P.H) && nl < P.Cout;
+                        float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[m][t][j] + bj[t][j];
-                    if (!valid) continue;
+                        for (int j = 0; j < 4; ++j) v[j] = acc[m][t][j] + bj[t][j];
+                        if (!valid) continue;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { ssum[t][j] += v[j]; ssq[t][j] += v[j] * v[j]; }
-                    if (CHAP_ABLATE & 8) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
-                    if (P.out_planar) {
-                        float* o = (float*)P.out + o0 + row * orow + ooff[t];
+                        for (int j = 0; j < 4; ++j) { ssum[t][j] += v[j]; ssq[t][j] += v[j] * v[j]; }
+                        const long oi = o0 + row * orow + zw_off + ooff[t];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (nl + j < P.Cout) o[(nl + j) * plane] = v[j];
-                    } else {
-                        const long oi = o0 + row * orow + ooff[t];
-                        if (nl + 3 < P.Cout) {
-                            if (P.out_f32) st4((float*)P.out + oi, v); else st4((T*)P.out + oi, v);
-                        } else {
+                        for (int j = 0; j < 4; ++j) if (nl + j < P.Cout) {
+                            if (P.out_planar) ((float*)P.out)[oi + (nl + j) * plane] = v[j];
+                            else if (P.out_f32) ((float*)P.out)[oi + j] = v[j];
+                            else ((T*)P.out)[oi + j] = elem<T>::put(v[j]);
+                        }
+                    }
+                }
+            } else {
+                // channel-last, 4 channels per lane: vector stores at (uniform base) + (32-bit lane offset)
+                char* ob = (char*)P.out + o0 * (P.out_f32 ? 4 : (long)sizeof(T));
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) if (nl + j < P.Cout) {
-                                if (P.out_f32) ((float*)P.out)[oi + j] = v[j]; else ((T*)P.out)[oi + j] = elem<T>::put(v[j]);
-                            }
+                for (int t = 0; t < NT; ++t) {
+                    const bool cok = (nt0 + t) * 16 + 4 * g < P.Cout;
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) {
+                        const int row = ZW ? m : wave * MR + m;
+                        const bool valid = xok && zok && cok && (y0 + row < P.H);
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[m][t][j] + bj[t][j];
+                        if (do_stats) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { const float vs = valid ? v[j] : 0.f; ssum[t][j] += vs; ssq[t][j] += vs * vs; }
+                        }
+                        if (CHAP_ABLATE & 8) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
+                        const unsigned oi = (unsigned)(row * orow + zw_off + ooff[t]);
+                        if (valid) {
+                            if (P.out_f32) st4((float*)(ob + oi * 4u), v); else st4((T*)(ob + oi * (unsigned)sizeof(T)), v);
                         }
                     }
                 }
             }
-            ++tile_k;
         }
+        CHAP_STAMP(3);
         // ---- land the prefetched halo in the other buffer; one barrier per item
-        if (has_next) halo_commit<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, nxt, s0, s1, aff, plain, nn, nchunk);
+        // (leaving BEFORE the commit keeps "prefetch issued but never waited for" off the loop's back edge: with
+        //  `if (has_next) commit` the compiler must assume the prefetch registers still have loads in flight at the
+        //  top of the next item and waits for every outstanding store before it issues the new loads)
+        if (!has_next) break;
+        halo_commit<T, KC, ADD2, UNITS>(R, U, nxt, s0, s1, aff, plain, nn, nchunk, lanesel);
         chunk = nchunk == nchunks ? 0 : nchunk;
+        CHAP_STAMP(4);
         __syncthreads();
+        CHAP_STAMP(5);
     }
 
     // ---- BatchNorm statistics: registers -> 16-lane shuffle -> LDS -> one atomic per channel per block

@@ -18,7 +18,7 @@ template <typename T> __host__ __device__ constexpr int wg_psb() { return sizeof
 template <typename T, int KS, int ST, bool D3, int KC, int MR>
 __host__ __device__ constexpr size_t wgrad_lds_bytes() {
     typedef conv_geom<KS, ST, D3, MR> G;
-    return 2 * ((size_t)G::HP * pix_stride<T, KC>() + (size_t)G::TH * G::TW * wg_psb<T>()) * sizeof(T)    // double-buffered A halo + B tile
+    return 2 * ((size_t)G::HP * pix_stride<T, KC>() + HALO_DUMMY + (size_t)G::TH * G::TW * wg_psb<T>()) * sizeof(T)    // double-buffered A halo + B tile
            + 3 * CONV_MAX_AFFINE_C * sizeof(float) + 4 * WG_BN * sizeof(float);                            // affine caches (A0, A1, B), db partials
 }
 
@@ -39,10 +39,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
     constexpr int NKCH = G::TH * G::TW / 32;            // 32-pixel k-chunks per tile
     constexpr int UNITS = (G::HP * GPT + 255) / 256;
     constexpr int BUNITS = (G::TH * G::TW * (WG_BN / 8) + 255) / 256;
+    static_assert((G::TH * G::TW * (WG_BN / 8)) % 256 == 0, "B tile units must fill the block exactly");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* halo0 = (T*)smem;
-    T* halo1 = halo0 + (size_t)G::HP * PS;
-    T* bt0 = halo1 + (size_t)G::HP * PS;
+    T* halo1 = halo0 + (size_t)G::HP * PS + HALO_DUMMY;
+    T* bt0 = halo1 + (size_t)G::HP * PS + HALO_DUMMY;
     T* bt1 = bt0 + (size_t)G::TH * G::TW * PSB;
     float* aff = (float*)(bt1 + (size_t)G::TH * G::TW * PSB);       // [A0 | A1 | B] x [scale | shift]
     float* dbred = aff + 3 * CONV_MAX_AFFINE_C;
@@ -63,19 +64,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
 
     // ---- one-time per thread: unit descriptors
     unit_desc<UNITS> U;
-#pragma unroll
-    for (int j = 0; j < UNITS; ++j) {
-        const int u = threadIdx.x + 256 * j;
-        U.hzyx[j] = -1; U.rel[j] = 0; U.lds[j] = 0; U.c8[j] = 0;
-        if (u < G::HP * GPT) {
-            const int pix = u / GPT, cgl = u % GPT;
-            const int hx = pix % G::HW, hy = (pix / G::HW) % G::HH, hz = pix / (G::HW * G::HH);
-            U.hzyx[j] = (hz << 20) | (hy << 10) | hx;
-            U.rel[j] = (hz * P.IH + hy) * P.IW + hx;
-            U.lds[j] = pix * PS + cgl * 8;
-            U.c8[j] = cgl * 8;
-        }
-    }
+    make_units<G, GPT, PS, UNITS>(U, P.IH, P.IW);
+    const bool lanesel = !ADD2 && P.na > 1 && (P.a[0].C % KC) != 0;
     int b_yx[BUNITS], b_rel[BUNITS], b_lds[BUNITS];     // B tile units: (row << 8 | col), pixel offset, LDS offset; channel = nb*32 + (tid % 4) * 8
     const int bc8 = (threadIdx.x & (WG_BN / 8 - 1)) * 8;
     const int cbB = nb * WG_BN + bc8;
@@ -114,46 +104,78 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
 
     halo_regs<T, UNITS, ADD2> R;
     F braw[BUNITS]; uint2 bkeep[BUNITS]; unsigned bok = 0;
+    f32x2 ba[4], bb2[4];                                        // scale/shift of this thread's 8 B channels
+    const int cbB_safe = bchan_ok ? cbB : 0;
 
+    // all loads unconditional (out-of-range units read the tile origin and are zeroed at commit): see halo_issue
     auto issue = [&](long tile, int& n, int& z0, int& y0, int& x0) {
-        tile_coords<G::TH, G::TW>(tile, tiles_x, tiles_y, P.D, n, z0, y0, x0);
-        halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, s0, s1, P.ID, P.IH, P.IW, n, z0, y0, x0, chunk);
+        tile_coords<G::TH, G::TW, 1>(tile, tiles_x, tiles_y, P.D, n, z0, y0, x0);
+        halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, s0, s1, P.ID, P.IH, P.IW, n, z0, y0, x0, chunk, lanesel);
         const long gp0 = (((long)n * P.D + z0) * P.H + y0) * P.W + x0;
-        const T* bb = (const T*)sb.ptr + gp0 * sb.ld + sb.coff + cbB;
-        const uint8_t* kb = sb.keep + gp0 * sb.C + cbB;
+        const char* bb = (const char*)sb.ptr + (gp0 * sb.ld + sb.coff + cbB_safe) * (long)sizeof(T);
+        const unsigned ldb = sb.ld * sizeof(T);
+        unsigned r[BUNITS];
         bok = 0;
 #pragma unroll
         for (int j = 0; j < BUNITS; ++j) {
             const int d = b_yx[j];
-            if (d >= 0 && bchan_ok && y0 + (d >> 8) < P.H && x0 + (d & 255) < P.W) {
-                bok |= 1u << j;
-                braw[j] = frag<T>::load(bb + b_rel[j] * sb.ld);
-                if (sb.has_keep) bkeep[j] = *(const uint2*)(kb + b_rel[j] * sb.C);
-            }
+            const bool ok = d >= 0 && bchan_ok && y0 + (d >> 8) < P.H && x0 + (d & 255) < P.W;
+            bok |= ok ? (1u << j) : 0u;
+            r[j] = ok ? (unsigned)b_rel[j] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < BUNITS; ++j) braw[j] = frag<T>::load((const T*)(bb + __umul24(r[j], ldb)));
+        if (sb.has_keep) {
+            const uint8_t* kb = sb.keep + gp0 * sb.C + cbB_safe;
+#pragma unroll
+            for (int j = 0; j < BUNITS; ++j) bkeep[j] = *(const uint2*)(kb + __umul24(r[j], (unsigned)sb.C));
         }
     };
     auto commit = [&](T* halo, T* bt, int n) {
-        halo_commit<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, halo, s0, s1, aff, plainA, n, chunk);
+        halo_commit<T, KC, ADD2, UNITS>(R, U, halo, s0, s1, aff, plainA, n, chunk, lanesel);
+        f32x2 a[4], b[4];
 #pragma unroll
-        for (int j = 0; j < BUNITS; ++j) {
-            if (b_yx[j] < 0) continue;
+        for (int k = 0; k < 4; ++k) { a[k] = ba[k]; b[k] = bb2[k]; }
+        if (sb.has_cm) {
+            float bcm[8];
+            ld8(sb.chan_mul + (long)n * sb.C + cbB_safe, bcm);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const f32x2 m = {bcm[2 * k], bcm[2 * k + 1]}; a[k] *= m; b[k] *= m; }
+        }
+#pragma unroll
+        for (int j = 0; j < BUNITS; ++j) {                      // (TH*16*4) % 256 == 0: every thread has all BUNITS units
             T* dst = bt + b_lds[j];
-            if (!((bok >> j) & 1u)) { frag<T>::store(dst, frag<T>::zero()); continue; }
+            const bool ok = (bok >> j) & 1u;
+            if (plainB) {
+                if (want_db) {
+                    float v[8];
+                    frag<T>::unpack(braw[j], v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) dbsum[k] += ok ? v[k] : 0.f;
+                }
+                frag<T>::store(dst, frag<T>::select(ok, braw[j]));
+                continue;
+            }
             float v[8];
             frag<T>::unpack(braw[j], v);
-            if (!plainB) lazy_transform(v, aff + 2 * CONV_MAX_AFFINE_C, cbB, sb.slope_eff, sb.has_keep, bkeep[j], sb.keep_scale,
-                                        sb.has_cm ? sb.chan_mul + (long)n * sb.C : nullptr);
+            affine_act8(v, a, b, sb.slope_eff);
+            if (sb.has_keep) keep8(v, bkeep[j], sb.keep_scale);
             if (want_db) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) dbsum[k] += v[k];
+                for (int k = 0; k < 8; ++k) dbsum[k] += ok ? v[k] : 0.f;
             }
-            if (plainB) frag<T>::store(dst, braw[j]); else st8(dst, v);
+            frag<T>::store(dst, frag<T>::select(ok, frag<T>::pack(v)));
         }
     };
 
     int n = 0, z0 = 0, y0 = 0, x0 = 0;
     if (my_tiles > 0) issue(split, n, z0, y0, x0);
-    __syncthreads();
+    __syncthreads();                                            // affine caches visible
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ba[k] = *(const f32x2*)(aff + 2 * CONV_MAX_AFFINE_C + cbB_safe + 2 * k);
+        bb2[k] = *(const f32x2*)(aff + 2 * CONV_MAX_AFFINE_C + CONV_MAX_AFFINE_C / 2 + cbB_safe + 2 * k);
+    }
     if (my_tiles > 0) commit(halo0, bt0, n);
     __syncthreads();
 
@@ -211,7 +233,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
                 }
             }
         }
-        if (has_next) commit((k & 1) ? halo0 : halo1, (k & 1) ? bt0 : bt1, n);
+        if (!has_next) break;                                   // see conv_fwd_kernel: keeps the prefetch wait-free
+        commit((k & 1) ? halo0 : halo1, (k & 1) ? bt0 : bt1, n);
         __syncthreads();
     }
     // ---- partial slab: ws[split][tap][kc_global][kn_global]; lane holds rows 4g+j (kc), col l15 (kn) ----

@@ -7,13 +7,13 @@
 #include <cstdlib>
 void chap_set_error(const char* fmt, ...) {}
 
-template <int KS, int KC, int NT, int MR, bool WLDS>
-static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool prologue, bool stats) {
+template <int KS, int KC, int NT, int MR, bool WLDS, bool D3 = false, bool ZW = false>
+static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool prologue, bool stats, int D = 1) {
     typedef uint16_t T;
-    typedef conv_geom<KS, 1, false, MR> G;
+    typedef conv_geom<KS, 1, D3, MR, ZW> G;
     constexpr int GPT = KC / 8, NP = G::NTAPS * GPT, STEPS = (NP + 3) / 4;
     const int nchunks = Cin / KC, ntile16 = (Cout + 15) / 16;
-    size_t nin = (size_t)N * H * W * Cin, nout = (size_t)N * H * W * Cout;
+    size_t nin = (size_t)N * D * H * W * Cin, nout = (size_t)N * D * H * W * Cout;
     T *x, *y, *wp; float *sc, *sh, *st;
     hipMalloc(&x, nin * 2); hipMalloc(&y, nout * 2);
     size_t wbytes_all = (size_t)nchunks * STEPS * ntile16 * 64 * 8 * 2;
@@ -27,15 +27,15 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
     chap_conv_params P = {};
     P.src[0].ptr = x; P.src[0].C = Cin; P.src[0].ld = Cin; P.src[0].slope = 0.01f; P.src[0].keep_scale = 1.f;
     if (prologue) { P.src[0].scale = sc; P.src[0].shift = sh; P.src[0].act = 1; }
-    P.nsrc = 1; P.N = N; P.D = 1; P.H = H; P.W = W; P.ID = 1; P.IH = H; P.IW = W; P.ksize = KS; P.stride = 1; P.dims = 2;
+    P.nsrc = 1; P.N = N; P.D = D; P.H = H; P.W = W; P.ID = D; P.IH = H; P.IW = W; P.ksize = KS; P.stride = 1; P.dims = D3 ? 3 : 2;
     P.wpacked = wp; P.out = y; P.Cout = Cout; P.out_ld = Cout; P.stats = stats ? st : nullptr; P.stats_reps = 8; P.dtype = CHAP_BF16;
-    auto kern = conv_fwd_kernel<T, KS, 1, false, KC, NT, MR, false, WLDS>;
-    size_t lds = conv_lds_fixed_bytes<T, KS, 1, false, KC, MR>(NT) + 2 * CONV_MAX_AFFINE_C * 4 + (WLDS ? (size_t)nchunks * STEPS * NT * 1024 : 0);
+    auto kern = conv_fwd_kernel<T, KS, 1, D3, KC, NT, MR, false, WLDS, ZW>;
+    size_t lds = conv_lds_fixed_bytes<T, KS, 1, D3, KC, MR, ZW>(NT) + 2 * CONV_MAX_AFFINE_C * 4 + (WLDS ? (size_t)nchunks * STEPS * NT * 1024 : 0);
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, lds);
-    long ntiles = (long)N * ((H + G::TH - 1) / G::TH) * ((W + 15) / 16);
+    long ntiles = (long)N * ((D + G::TD - 1) / G::TD) * ((H + G::TH - 1) / G::TH) * ((W + 15) / 16);
     int gy = (ntile16 + NT - 1) / NT;
-    for (int bpc = 1; bpc <= 8; bpc *= 2) {
+    for (int bpc = 1; bpc <= (D3 ? 2 : 8); bpc *= 2) {
         long gx = std::min<long>((ntiles + 7) / 8 * 8, (long)256 * bpc / gy / 8 * 8);
         if (gx < 8) gx = 8;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -45,12 +45,34 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         double us = ms * 1e3 / 20, gb = (double)(nin + nout) * 2 / us / 1e3;
+#ifdef CHAP_CONV_TRACE
+        if (gx >= 1024 || D3) {
+            unsigned long long h[4][64][8];
+            hipMemcpyFromSymbol(h, HIP_SYMBOL(chap_trace), sizeof(h));
+            for (int b = 0; b < 2; ++b) for (int w = 0; w < 2; ++w) {
+                printf("  block %d wave %d (100 MHz ticks -> us):", b * 257, w);
+                for (int it = 0; it < 4; ++it) {
+                    unsigned long long* r = h[b][it * 4 + w];
+                    printf(" | it%d issue %.2f mfma %.2f epi %.2f commit %.2f bar %.2f", it, (r[1]-r[0])/100., (r[2]-r[1])/100., (r[3]-r[2])/100., (r[4]-r[3])/100., (r[5]-r[4])/100.);
+                }
+                printf("\n");
+            }
+        }
+#endif
         printf("mw=%d abl=%2d %-28s occ=%d grid=%5ldx%d lds=%6zu : %8.1f us %7.1f GB/s\n", CHAP_CONV_MINWAVES, CHAP_ABLATE, name, occ, gx, gy, lds, us, gb);
     }
     hipFree(x); hipFree(y); hipFree(wp); hipFree(sc); hipFree(sh); hipFree(st);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == '3') {
+        run<3, 16, 1, 4, true, true, true>("3D 16->16@80x112x112 ZW", 2, 112, 112, 16, 16, true, true, 80);
+        run<3, 32, 2, 4, true, true, true>("3D 32->32@40x56x56 ZW", 2, 56, 56, 32, 32, true, true, 40);
+        run<3, 32, 4, 1, false, true, false>("3D 64->64@20x28x28 MR1", 4, 28, 28, 64, 64, true, true, 20);
+        run<3, 32, 4, 4, false, true, true>("3D 64->64@20x28x28 ZW", 4, 28, 28, 64, 64, true, true, 20);
+        run<3, 32, 4, 1, false, true, false>("3D 128->128@10x14x14 MR1", 4, 14, 14, 128, 128, true, true, 10);
+        return 0;
+    }
     run<3, 16, 1, 4, true>("16->16@256 MR4 pro+stats", 12, 256, 256, 16, 16, true, true);
     run<3, 16, 1, 2, true>("16->16@256 MR2 pro+stats", 12, 256, 256, 16, 16, true, true);
     run<3, 32, 2, 4, true>("32->32@128 MR4 pro+stats", 12, 128, 128, 32, 32, true, true);

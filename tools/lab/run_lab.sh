@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../.."
 mkdir -p gpurun_out/lab
 for a in ${1:-0}; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Ichap_amd/csrc -DCHAP_ABLATE=$a ${LABFLAGS} tools/lab/conv_lab.hip -o gpurun_out/lab/conv_lab_$a &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Ichap_amd/csrc -DCHAP_ABLATE=$a ${LABFLAGS} tools/lab/conv_lab.hip -w -o gpurun_out/lab/conv_lab_$a &
 done
 wait
-for a in ${1:-0}; do ./gpurun_out/lab/conv_lab_$a; done
+for a in ${1:-0}; do ./gpurun_out/lab/conv_lab_$a ${LABARGS}; done
