@@ -57,17 +57,31 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     // weight reuse) when the layer has plenty of pixels; small tiles when it would not fill 256 CUs.
     int NT = b.ntiles >= 4 ? 4 : (b.ntiles >= 2 ? 2 : 1);
     int MR = (geom == 2 || geom == 5) ? 1 : 2;
-    if (geom == 2 && p->dtype == CHAP_BF16 && (long)p->N * cdiv(p->D, 4) * cdiv(p->H, 4) * cdiv(p->W, 16) * cdiv(b.ntiles, NT) >= 256) MR = 4;   // z-per-wave bricks
+    const bool bf = p->dtype == CHAP_BF16;
+    if (geom == 2 && bf) {
+        // 3D 3x3x3 (measured on the V-Net shapes, tools/lab/conv_lab.hip sweeps): z-per-wave bricks (MR = 4) once
+        // the grid has >= 32 bricks, with the widest NT that still gives >= 128 blocks; the deep, tiny layers run
+        // 1 x 4 x 16 slabs with NT = 2 (two blocks per CU, weights staged through LDS).
+        const long bricks = (long)p->N * cdiv(p->D, 4) * cdiv(p->H, 4) * cdiv(p->W, 16);
+        if (bricks >= 32) {
+            MR = 4;
+            while (NT > 1 && bricks * cdiv(b.ntiles, NT) < 128) NT >>= 1;
+        } else if (b.KC == 32 && NT > 2) {
+            NT = 2;
+        }
+    }
     if (geom == 1 || geom == 3) {
-        const long px = (long)p->N * p->D * p->H * p->W;
         auto blocks = [&](int mr, int nt) { return (long)p->N * p->D * cdiv(p->H, 4 * mr) * cdiv(p->W, 16) * cdiv(b.ntiles, nt); };
-        if (geom == 1 && b.KC == 16 && blocks(4, NT) >= 512) MR = 4;
+        if (geom == 1 && bf && b.KC == 32 && b.ntiles >= 4) {
+            // deep 2D layers (Cout >= 64): 8 x 16 tiles x 32 channels -- two blocks per CU hide each other's
+            // staging latency and the staged weights fit; best or within 5% of best for 64@64 .. 256@16, N = 12 / 24
+            MR = 2; NT = 2;
+        } else if (geom == 1 && b.KC == 16 && blocks(4, NT) >= 512) MR = 4;
         else if (blocks(2, NT) >= 384) MR = 2;
         else {
             MR = 1;
             while (NT > 1 && blocks(1, NT) < 384) NT >>= 1;
         }
-        (void)px;
     }
     static const conv_launch_fn table[2][5] = {
         {chap_conv_launch_f32_g1, chap_conv_launch_f32_g2, chap_conv_launch_f32_g3, chap_conv_launch_f32_g4, chap_conv_launch_f32_g5},

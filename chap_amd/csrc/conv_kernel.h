@@ -25,8 +25,11 @@
 #ifdef CHAP_CONV_TRACE         // lab only: per-phase s_memtime stamps of one wave per traced block
 __device__ unsigned long long chap_trace[4][64][8];
 #define CHAP_STAMP(k) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x % 257) == 0 && blockIdx.x / 257 < 4 && it < 8) chap_trace[blockIdx.x / 257][it * 4 + (threadIdx.x >> 6)][k] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long chap_trace_p[4][4][8];
+#define CHAP_STAMP_P(k) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x % 257) == 0 && blockIdx.x / 257 < 4) chap_trace_p[blockIdx.x / 257][threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define CHAP_STAMP(k) do {} while (0)
+#define CHAP_STAMP_P(k) do {} while (0)
 #endif
 
 template <int KC> struct lds_pix_stride {};        // LDS pixel stride in elements, conflict-free for
@@ -57,6 +60,16 @@ template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ZW = false>
 __host__ __device__ constexpr size_t conv_lds_fixed_bytes(int NT) {
     return 2 * ((size_t)conv_geom<KS, ST, D3, MR, ZW>::HP * pix_stride<T, KC>() + HALO_DUMMY) * sizeof(T)   // two halo buffers
            + 2 * 16 * NT * sizeof(float);                                                // block statistics
+}
+
+// Weights that do not fit LDS whole are staged per item (one K-chunk: STEPS x NT fragment blocks) through
+// registers into a double buffer, like the halo -- when that takes <= 14 fragments per thread and fits.
+template <typename T, int KS, int ST, bool D3, int KC, int NT, int MR, bool ZW>
+__host__ __device__ constexpr bool conv_wstaged() {
+    typedef conv_geom<KS, ST, D3, MR, ZW> G;
+    constexpr int STEPS = (G::NTAPS * (KC / 8) + 3) / 4;
+    return (STEPS * NT + 3) / 4 <= 14 &&
+           conv_lds_fixed_bytes<T, KS, ST, D3, KC, MR, ZW>(NT) + 2 * CONV_MAX_AFFINE_C * sizeof(float) + 2 * (size_t)STEPS * NT * 512 * sizeof(T) <= 158 * 1024;
 }
 
 // ---- MFMA wrappers: acc += W(8 k-values of one cout) x X(8 k-values of one pixel) ---------------
@@ -359,18 +372,19 @@ __device__ __forceinline__ void tile_coords(long tile, int tiles_x, int tiles_y,
 }
 
 template <typename T, int KS, int ST, bool D3, int KC, int NT, int MR, bool ADD2, bool WLDS, bool ZW = false>
-__global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES : (KC == 16 && !D3 ? 4 : 1))) void conv_fwd_kernel(const chap_conv_params P) {
+__global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES : (KC == 16 && !D3 ? 3 : 1))) void conv_fwd_kernel(const chap_conv_params P) {
     typedef conv_geom<KS, ST, D3, MR, ZW> G;
     typedef typename frag<T>::type F;
     constexpr int GPT = KC / 8, PS = pix_stride<T, KC>();
     constexpr int NP = G::NTAPS * GPT, STEPS = (NP + 3) / 4;
     constexpr int UNITS = (G::HP * GPT + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    CHAP_STAMP_P(0);
     T* halo0 = (T*)smem;
     T* halo1 = halo0 + (size_t)G::HP * PS + HALO_DUMMY;
     float* bstat = (float*)(halo1 + (size_t)G::HP * PS + HALO_DUMMY);
     float* aff = bstat + 2 * 16 * NT;                       // [2 sources][scale | shift][CONV_MAX_AFFINE_C/2]
-    T* wlds = (T*)(aff + 2 * CONV_MAX_AFFINE_C);            // WLDS only
+    T* wlds = (T*)(aff + 2 * CONV_MAX_AFFINE_C);            // WLDS: all weights; staged mode: two buffers of one K-chunk's weights
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
@@ -448,6 +462,35 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         }
     }
     const long wstep = (long)ntiles_total * 64 * 8;             // packed elements per (chunk, step)
+    // Staged weights (layers whose weights do not fit LDS whole): the STEPS x NT fragment blocks (already in lane
+    // order) of ONE K-chunk are prefetched into registers next to the halo and written to the LDS buffer the
+    // NEXT item reads.  Streaming them from L2 inside the tap loop exposes a load latency per step.
+    constexpr bool WST = !WLDS && conv_wstaged<T, KS, ST, D3, KC, NT, MR, ZW>();
+    constexpr int WFR = WST ? (STEPS * NT + 3) / 4 : 1;          // fragments per thread (wave w takes blocks w, w+4, ..)
+    F wreg[WFR];
+    auto wstage_issue = [&](int chunk_) {
+        if constexpr (WST) {
+            const T* src = (const T*)P.wpacked + (long)chunk_ * STEPS * wstep + lane * 8;
+#pragma unroll
+            for (int k = 0; k < WFR; ++k) {
+                const int i = min(4 * k + wave, STEPS * NT - 1);  // clamp (wave-uniform): no branch around the load
+                const int step = i / NT, t = i % NT;
+                const int tt = nt0 + t < ntiles_total ? nt0 + t : nt0;          // clamp: those channels are never stored
+                wreg[k] = frag<T>::load(src + (long)step * wstep + (long)tt * 512);
+            }
+        }
+    };
+    auto wstage_commit = [&](int buf) {
+        if constexpr (WST) {
+            T* dst = wlds + (size_t)buf * (STEPS * NT * 512) + lane * 8;
+#pragma unroll
+            for (int k = 0; k < WFR; ++k) {
+                const int i = min(4 * k + wave, STEPS * NT - 1);  // clamped waves rewrite the last block with identical data: every prefetch register is consumed on every path
+                frag<T>::store(dst + i * 512, wreg[k]);
+            }
+        }
+    };
+    if (WST && nitems > 0) wstage_issue(0);
     // resident weights: [chunk][step][t < NT][64 lanes][8]; first batch of 8 fragments per thread in flight now
     const long wtot = WLDS ? (long)nchunks * STEPS * NT * 64 : 0;
     auto wload = [&](long i) -> F {
@@ -537,9 +580,12 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     }
 
     int n = 0, z0 = 0, y0 = 0, x0 = 0;
+    CHAP_STAMP_P(1);
     __syncthreads();                                            // affine cache (+ resident weights) visible
-    if (nitems > 0) halo_commit<T, KC, ADD2, UNITS>(R, U, halo0, s0, s1, aff, plain, nn, 0, lanesel);
+    CHAP_STAMP_P(2);
+    if (nitems > 0) { halo_commit<T, KC, ADD2, UNITS>(R, U, halo0, s0, s1, aff, plain, nn, 0, lanesel); wstage_commit(0); }
     __syncthreads();
+    CHAP_STAMP_P(3);
 
     int chunk = 0;
     for (long it = 0; it < nitems; ++it) {
@@ -565,17 +611,18 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
                 nn += sn + c;
             }
             halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, ntz * G::TD, nty * G::TH, ntx * G::TW, nchunk, lanesel);
+            wstage_issue(nchunk);
         }
         CHAP_STAMP(1);
         // ---- MFMA over the taps of this chunk
         const T* wc_g = (const T*)P.wpacked + (long)chunk * STEPS * wstep + ((long)nt0 * 64 + lane) * 8;
-        const T* wc_l = wlds + ((long)chunk * STEPS * NT * 64 + lane) * 8;
+        const T* wc_l = wlds + ((long)(WLDS ? chunk : (int)(it & 1)) * STEPS * NT * 64 + lane) * 8;
 #pragma unroll
         for (int step = 0; step < ((CHAP_ABLATE & 2) ? 0 : STEPS); ++step) {
             F wf[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                if (WLDS) wf[t] = frag<T>::load(wc_l + ((long)step * NT + t) * 512);
+                if (WLDS || WST) wf[t] = frag<T>::load(wc_l + ((long)step * NT + t) * 512);
                 else wf[t] = (nt0 + t < ntiles_total) ? frag<T>::load(wc_g + (long)step * wstep + t * 512) : frag<T>::zero();
             }
             const int xo = xoff[step];
@@ -659,12 +706,14 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         //  top of the next item and waits for every outstanding store before it issues the new loads)
         if (!has_next) break;
         halo_commit<T, KC, ADD2, UNITS>(R, U, nxt, s0, s1, aff, plain, nn, nchunk, lanesel);
+        wstage_commit((int)((it + 1) & 1));
         chunk = nchunk == nchunks ? 0 : nchunk;
         CHAP_STAMP(4);
         __syncthreads();
         CHAP_STAMP(5);
     }
 
+    CHAP_STAMP_P(4);
     // ---- BatchNorm statistics: registers -> 16-lane shuffle -> LDS -> one atomic per channel per block
     if (do_stats) {
         for (int i = threadIdx.x; i < 2 * 16 * NT; i += 256) bstat[i] = 0.f;
@@ -692,4 +741,5 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
             if (nl < P.Cout) atomicAdd(&st[which * Cs + (P.out_mode == 1 ? nl % P.out_Cn : nl)], bstat[i]);
         }
     }
+    CHAP_STAMP_P(5);
 }

@@ -2,7 +2,7 @@
 prologue + statistics epilogue) a few times -- the target of the rocprofv3 --pmc passes that give
 `roofline.traffic` (FETCH_SIZE / WRITE_SIZE must be collected in separate passes on gfx950)."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 

@@ -30,12 +30,16 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
     P.nsrc = 1; P.N = N; P.D = D; P.H = H; P.W = W; P.ID = D; P.IH = H; P.IW = W; P.ksize = KS; P.stride = 1; P.dims = D3 ? 3 : 2;
     P.wpacked = wp; P.out = y; P.Cout = Cout; P.out_ld = Cout; P.stats = stats ? st : nullptr; P.stats_reps = 8; P.dtype = CHAP_BF16;
     auto kern = conv_fwd_kernel<T, KS, 1, D3, KC, NT, MR, false, WLDS, ZW>;
-    size_t lds = conv_lds_fixed_bytes<T, KS, 1, D3, KC, MR, ZW>(NT) + 2 * CONV_MAX_AFFINE_C * 4 + (WLDS ? (size_t)nchunks * STEPS * NT * 1024 : 0);
+    size_t lds_fixed_only = conv_lds_fixed_bytes<T, KS, 1, D3, KC, MR, ZW>(NT) + 2 * CONV_MAX_AFFINE_C * 4;
+    const bool fits = conv_wstaged<T, KS, 1, D3, KC, NT, MR, ZW>();
+    const int wstage = WLDS || fits;
+    size_t lds = conv_lds_fixed_bytes<T, KS, 1, D3, KC, MR, ZW>(NT) + 2 * CONV_MAX_AFFINE_C * 4 + (WLDS ? (size_t)nchunks * STEPS * NT * 1024 : (wstage ? 2 * (size_t)STEPS * NT * 1024 : 0));
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, lds);
     long ntiles = (long)N * ((D + G::TD - 1) / G::TD) * ((H + G::TH - 1) / G::TH) * ((W + 15) / 16);
     int gy = (ntile16 + NT - 1) / NT;
     for (int bpc = 1; bpc <= (D3 ? 2 : 8); bpc *= 2) {
+        if (bpc > 1 && bpc > occ) break;
         long gx = std::min<long>((ntiles + 7) / 8 * 8, (long)256 * bpc / gy / 8 * 8);
         if (gx < 8) gx = 8;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -46,7 +50,7 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
         float ms; hipEventElapsedTime(&ms, e0, e1);
         double us = ms * 1e3 / 20, gb = (double)(nin + nout) * 2 / us / 1e3;
 #ifdef CHAP_CONV_TRACE
-        if (gx >= 1024 || D3) {
+        if (gx >= 1024 || D3 || getenv("LAB_TRACE_ALL")) {
             unsigned long long h[4][64][8];
             hipMemcpyFromSymbol(h, HIP_SYMBOL(chap_trace), sizeof(h));
             for (int b = 0; b < 2; ++b) for (int w = 0; w < 2; ++w) {
@@ -57,6 +61,11 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
                 }
                 printf("\n");
             }
+            unsigned long long hp[4][4][8];
+            hipMemcpyFromSymbol(hp, HIP_SYMBOL(chap_trace_p), sizeof(hp));
+            unsigned long long t0 = hp[0][0][0];
+            for (int b = 0; b < 4; ++b) { unsigned long long* r = hp[b][0];
+                printf("  block %d: start %+.2f | loads issued %.2f | barrier %.2f | first commit %.2f | item loop %.2f | stats flush %.2f | total %.2f\n", b * 257, ((double)r[0] - (double)t0) / 100., (r[1]-r[0])/100., (r[2]-r[1])/100., (r[3]-r[2])/100., (r[4]-r[3])/100., (r[5]-r[4])/100., (r[5]-r[0])/100.); }
         }
 #endif
         printf("mw=%d abl=%2d %-28s occ=%d grid=%5ldx%d lds=%6zu : %8.1f us %7.1f GB/s\n", CHAP_CONV_MINWAVES, CHAP_ABLATE, name, occ, gx, gy, lds, us, gb);
@@ -64,7 +73,31 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
     hipFree(x); hipFree(y); hipFree(wp); hipFree(sc); hipFree(sh); hipFree(st);
 }
 
+template <int KC, bool D3, bool ZW, int MR> static void sweep_nt(const char* tag, int N, int D, int H, int W, int C) {
+    char nm[64];
+    snprintf(nm, 64, "%s MR%d NT4", tag, MR); run<3, KC, 4, MR, false, D3, ZW>(nm, N, H, W, C, C, true, true, D);
+    snprintf(nm, 64, "%s MR%d NT2", tag, MR); run<3, KC, 2, MR, false, D3, ZW>(nm, N, H, W, C, C, true, true, D);
+    snprintf(nm, 64, "%s MR%d NT1", tag, MR); run<3, KC, 1, MR, false, D3, ZW>(nm, N, H, W, C, C, true, true, D);
+}
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 's') {       // blocking sweep on the deep layers
+        for (int N : {12, 24}) {
+            char t[32];
+            snprintf(t, 32, "64@64 N%d", N);  sweep_nt<32, false, false, 4>(t, N, 1, 64, 64, 64); sweep_nt<32, false, false, 2>(t, N, 1, 64, 64, 64); sweep_nt<32, false, false, 1>(t, N, 1, 64, 64, 64);
+            snprintf(t, 32, "128@32 N%d", N); sweep_nt<32, false, false, 4>(t, N, 1, 32, 32, 128); sweep_nt<32, false, false, 2>(t, N, 1, 32, 32, 128); sweep_nt<32, false, false, 1>(t, N, 1, 32, 32, 128);
+            snprintf(t, 32, "256@16 N%d", N); sweep_nt<32, false, false, 4>(t, N, 1, 16, 16, 256); sweep_nt<32, false, false, 2>(t, N, 1, 16, 16, 256); sweep_nt<32, false, false, 1>(t, N, 1, 16, 16, 256);
+        }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 't') {       // 3D deep layers
+        for (int N : {2, 4}) {
+            char t[32];
+            snprintf(t, 32, "3D 64@20x28x28 N%d", N);  sweep_nt<32, true, false, 1>(t, N, 20, 28, 28, 64); sweep_nt<32, true, true, 4>(t, N, 20, 28, 28, 64);
+            snprintf(t, 32, "3D 128@10x14x14 N%d", N); sweep_nt<32, true, false, 1>(t, N, 10, 14, 14, 128); sweep_nt<32, true, true, 4>(t, N, 10, 14, 14, 128);
+            snprintf(t, 32, "3D 256@5x7x7 N%d", N);    sweep_nt<32, true, false, 1>(t, N, 5, 7, 7, 256); sweep_nt<32, true, true, 4>(t, N, 5, 7, 7, 256);
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == '3') {
         run<3, 16, 1, 4, true, true, true>("3D 16->16@80x112x112 ZW", 2, 112, 112, 16, 16, true, true, 80);
         run<3, 32, 2, 4, true, true, true>("3D 32->32@40x56x56 ZW", 2, 56, 56, 32, 32, true, true, 40);
