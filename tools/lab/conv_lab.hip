@@ -89,6 +89,27 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (argc > 1 && argv[1][0] == 'k') {       // 3D: KC16 bricks vs KC32
+        run<3, 16, 2, 4, true, true, true>("3D 32->32@40x56x56 ZW KC16 NT2 WLDS", 2, 56, 56, 32, 32, true, true, 40);
+        run<3, 16, 2, 4, false, true, true>("3D 32->32@40x56x56 ZW KC16 NT2 stg", 2, 56, 56, 32, 32, true, true, 40);
+        run<3, 32, 2, 4, false, true, true>("3D 32->32@40x56x56 ZW KC32 NT2", 2, 56, 56, 32, 32, true, true, 40);
+        run<3, 16, 1, 4, true, true, true>("3D 32->16@80x112x112 ZW KC16 NT1 WLDS", 2, 112, 112, 32, 16, true, true, 80);
+        run<3, 32, 1, 4, false, true, true>("3D 32->16@80x112x112 ZW KC32 NT1", 2, 112, 112, 32, 16, true, true, 80);
+        for (int N : {2, 4}) {
+            char t[48];
+            snprintf(t, 48, "3D 64@20x28x28 N%d ZW KC16 NT2", N); run<3, 16, 2, 4, false, true, true>(t, N, 28, 28, 64, 64, true, true, 20);
+            snprintf(t, 48, "3D 64@20x28x28 N%d ZW KC32 NT4", N); run<3, 32, 4, 4, false, true, true>(t, N, 28, 28, 64, 64, true, true, 20);
+            snprintf(t, 48, "3D 128@10x14x14 N%d ZW KC16 NT2", N); run<3, 16, 2, 4, false, true, true>(t, N, 14, 14, 128, 128, true, true, 10);
+            snprintf(t, 48, "3D 128@10x14x14 N%d ZW KC32 NT2", N); run<3, 32, 2, 4, false, true, true>(t, N, 14, 14, 128, 128, true, true, 10);
+        }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'h') {       // 3D half-resolution layer
+        run<3, 32, 2, 4, false, true, true>("3D 32->32@40x56x56 ZW NT2", 2, 56, 56, 32, 32, true, true, 40);
+        run<3, 32, 2, 1, false, true, false>("3D 32->32@40x56x56 MR1 NT2", 2, 56, 56, 32, 32, true, true, 40);
+        run<3, 32, 1, 4, false, true, true>("3D 32->16@80x112x112 ZW NT1", 2, 112, 112, 32, 16, true, true, 80);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 't') {       // 3D deep layers
         for (int N : {2, 4}) {
             char t[32];
