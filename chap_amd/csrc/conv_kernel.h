@@ -617,25 +617,35 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         // ---- MFMA over the taps of this chunk
         const T* wc_g = (const T*)P.wpacked + (long)chunk * STEPS * wstep + ((long)nt0 * 64 + lane) * 8;
         const T* wc_l = wlds + ((long)(WLDS ? chunk : (int)(it & 1)) * STEPS * NT * 64 + lane) * 8;
-#pragma unroll
-        for (int step = 0; step < ((CHAP_ABLATE & 2) ? 0 : STEPS); ++step) {
-            F wf[NT];
+        // software-pipelined: the fragments of step s+1 are requested before the MFMAs of step s are issued, so
+        // the LDS (or L2) latency hides behind MR*NT MFMAs instead of preceding every one of them
+        auto load_step = [&](int step, F (&wf)[NT], F (&xf)[MR]) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (WLDS || WST) wf[t] = frag<T>::load(wc_l + ((long)step * NT + t) * 512);
-                else wf[t] = (nt0 + t < ntiles_total) ? frag<T>::load(wc_g + (long)step * wstep + t * 512) : frag<T>::zero();
+                else wf[t] = frag<T>::load(wc_g + (long)step * wstep + (nt0 + t < ntiles_total ? t : 0) * 512);   // clamped: those channels are never stored
             }
             const int xo = xoff[step];
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                F xf;
-                if (step * 4 + 3 < NP) xf = frag<T>::load(cur + xo + m * (ST * G::HW * PS));        // every lane group has a tap
-                else xf = xo >= 0 ? frag<T>::load(cur + xo + m * (ST * G::HW * PS)) : frag<T>::zero();
+                if (step * 4 + 3 < NP) xf[m] = frag<T>::load(cur + xo + m * (ST * G::HW * PS));        // every lane group has a tap
+                else xf[m] = xo >= 0 ? frag<T>::load(cur + xo + m * (ST * G::HW * PS)) : frag<T>::zero();
+            }
+        };
+        F wfa[NT], xfa[MR], wfb[NT], xfb[MR];
+        constexpr int NSTEP = (CHAP_ABLATE & 2) ? 0 : STEPS;
+        if (NSTEP > 0) load_step(0, wfa, xfa);
+#pragma unroll
+        for (int step = 0; step < NSTEP; ++step) {
+            if (step + 1 < NSTEP) { if (step & 1) load_step(step + 1, wfa, xfa); else load_step(step + 1, wfb, xfb); }
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    if (CHAP_ABLATE & 1) { float kx[8], kw[8]; frag<T>::unpack(xf, kx); frag<T>::unpack(wf[t], kw); asm volatile("" :: "v"(kx[0]), "v"(kx[7]), "v"(kw[0]), "v"(kw[7])); } else mma8(acc[m][t], wf[t], xf);
+                    const F& w = (step & 1) ? wfb[t] : wfa[t];
+                    const F& x = (step & 1) ? xfb[m] : xfa[m];
+                    if (CHAP_ABLATE & 1) { float kx[8], kw[8]; frag<T>::unpack(x, kx); frag<T>::unpack(w, kw); asm volatile("" :: "v"(kx[0]), "v"(kx[7]), "v"(kw[0]), "v"(kw[7])); } else mma8(acc[m][t], w, x);
                 }
-            }
         }
         CHAP_STAMP(2);
         // ---- epilogue after the last K-chunk of a tile: lane holds D[cout = 16*t + 4*g + j][pixel (row m, x = px)]
