@@ -36,41 +36,48 @@ extern "C" size_t chap_wgrad_ws(const chap_wgrad_params* p) {
     return q.bytes;
 }
 
-// Deterministic slab reduction: a block owns 8 consecutive elements and splits the slabs over
-// 32 thread groups; each thread keeps 4 independent partial sums so that 4 loads are in flight
-// (the loop is latency-bound otherwise).  Fixed summation order -> bitwise reproducible.
+// Deterministic slab reduction.  A block owns E4*4 consecutive elements (one float4 per thread column) and
+// splits the slabs over G = 256/E4 thread groups: group g sums slabs g, g+G, ... with 4 loads in flight, the G
+// partials are combined in a fixed order through LDS.  E4 = 64 (1 KB contiguous per wave-load, G = 4) for the
+// few-slab / large-weight layers, E4 = 8 (G = 32) when there are many slabs of a small weight.
+// Fixed summation order -> bitwise reproducible.  total % 4 == 0 (Cb is a multiple of 16).
 // Blocks [0, nb_dw) reduce dW, blocks [nb_dw, ...) reduce the bias-gradient partials the same way.
+template <int E4>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_db, int nsplit, int taps, int Ca, int Cb,
                                                            float* dw, long s_tap, long s_kc, long s_kn, int kc_valid, int kn_valid, float* db, int nb_dw) {
-    __shared__ float red[32][9];
-    const bool is_db = (int)blockIdx.x >= nb_dw;
-    const float* src = is_db ? ws_db : ws;
+    constexpr int G = 256 / E4;
+    __shared__ float4 red[G][E4];
+    const int col = threadIdx.x % E4, g = threadIdx.x / E4;
+    const bool is_db = (int)blockIdx.x >= nb_dw;                 // bias gradient: Cb values x nsplit partials, same scheme
     const long total = is_db ? (long)Cb : (long)taps * Ca * Cb;
-    const int e = threadIdx.x & 7, sg = threadIdx.x >> 3;
-    const long i = (long)(is_db ? blockIdx.x - nb_dw : blockIdx.x) * 8 + e;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const long i = ((long)(is_db ? blockIdx.x - nb_dw : blockIdx.x) * E4 + col) * 4;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
     if (i < total) {
-        int k = sg;
-        for (; k + 96 < nsplit; k += 128) {
-            s0 += src[(long)k * total + i];
-            s1 += src[(long)(k + 32) * total + i];
-            s2 += src[(long)(k + 64) * total + i];
-            s3 += src[(long)(k + 96) * total + i];
+        const float* src = (is_db ? ws_db : ws) + i;
+        int k = g;
+        for (; k + 3 * G < nsplit; k += 4 * G) {
+            const float4 a = *(const float4*)(src + (long)k * total), b = *(const float4*)(src + (long)(k + G) * total);
+            const float4 c = *(const float4*)(src + (long)(k + 2 * G) * total), d = *(const float4*)(src + (long)(k + 3 * G) * total);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;  s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+            s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;  s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
         }
-        for (; k < nsplit; k += 32) s0 += src[(long)k * total + i];
+        for (; k < nsplit; k += G) { const float4 a = *(const float4*)(src + (long)k * total); s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; }
     }
-    red[sg][e] = (s0 + s1) + (s2 + s3);
+    red[g][col] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
     __syncthreads();
-    if (sg == 0 && i < total) {
-        float t = 0.f;
+    if (g == 0 && i < total) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 32; ++k) t += red[k][e];
+        for (int k = 0; k < G; ++k) { const float4 a = red[k][col]; t[0] += a.x; t[1] += a.y; t[2] += a.z; t[3] += a.w; }
+        const int kn0 = (int)(i % Cb); const long r = i / Cb;            // 4 consecutive kn of one (tap, kc): Cb % 4 == 0
+        const int kc = (int)(r % Ca); const int tap = (int)(r / Ca);
         if (is_db) {
-            if (i < kn_valid) db[i] += t;
-        } else {
-            const int kn = (int)(i % Cb); const long r = i / Cb;
-            const int kc = (int)(r % Ca); const int tap = (int)(r / Ca);
-            if (kc < kc_valid && kn < kn_valid) dw[tap * s_tap + kc * s_kc + kn * s_kn] += t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (kn0 + j < kn_valid) db[kn0 + j] += t[j];
+        } else if (kc < kc_valid) {
+            float* o = dw + tap * s_tap + kc * s_kc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (kn0 + j < kn_valid) o[(kn0 + j) * s_kn] += t[j];
         }
     }
 }
@@ -93,9 +100,17 @@ extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     if (r) return r;
     const long total = (long)q.taps * q.Ca * q.Cb;
     const int kcv = p->kc_valid > 0 ? p->kc_valid : q.Ca, knv = p->kn_valid > 0 ? p->kn_valid : q.Cb;
-    const int nb_dw = cdiv(total, 8), nb_db = p->db ? cdiv(q.Cb, 8) : 0;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb_dw + nb_db), dim3(256), 0, s, (const float*)ws, (const float*)ws_db, q.nsplit, q.taps, q.Ca, q.Cb,
-                       p->dw, (long)p->s_tap, (long)p->s_kc, (long)p->s_kn, kcv, knv, p->db, nb_dw);
+    if (q.nsplit >= 64) {
+        const int nb_db = p->db ? cdiv(q.Cb, 32) : 0;
+        const int nb_dw = cdiv(total, 32);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(nb_dw + nb_db), dim3(256), 0, s, (const float*)ws, (const float*)ws_db, q.nsplit, q.taps, q.Ca, q.Cb,
+                           p->dw, (long)p->s_tap, (long)p->s_kc, (long)p->s_kn, kcv, knv, p->db, nb_dw);
+    } else {
+        const int nb_db = p->db ? cdiv(q.Cb, 256) : 0;
+        const int nb_dw = cdiv(total, 256);
+        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(nb_dw + nb_db), dim3(256), 0, s, (const float*)ws, (const float*)ws_db, q.nsplit, q.taps, q.Ca, q.Cb,
+                           p->dw, (long)p->s_tap, (long)p->s_kc, (long)p->s_kn, kcv, knv, p->db, nb_dw);
+    }
     CHAP_LAUNCH_CHECK("chap_wgrad(reduce)");
     return CHAP_OK;
 }
