@@ -67,6 +67,7 @@ class Saved:
         self.bnstat = {}     # bn prefix -> (mean, invstd, count)
         self.pool_idx = {}   # pooled value name -> idx tensor
         self.x = None
+        self.xpad = None     # bf16 mode: the input zero-padded to 16 channels (channel-last)
         self.train = False
 
 
@@ -108,7 +109,9 @@ class Executor:
         if op.kind == "deconv":
             return (L.PACK_DECONV_FWD, L.PACK_DECONV_DGRAD)
         if op.kind == "c1":
-            return (L.PACK_CONV_DGRAD,)          # dL/dx of the first layer (VAT) runs on the MFMA conv kernel: 16 -> 1 channel
+            # dL/dx of the first layer (VAT) runs on the MFMA conv kernel (16 -> 1 channel); in bf16 mode the forward
+            # does too, on the input zero-padded to 16 channels (the scalar 1-channel kernel is load-issue bound)
+            return (L.PACK_CONV_DGRAD, L.PACK_CONV_FWD)
         return ()
 
     def _build_pack_table(self, dtype, sd):
@@ -207,7 +210,15 @@ class Executor:
             if k == "c1":
                 gd = (D, H, W)
                 out = torch.empty(N, D, H, W, op.cout, dtype=dtype, device=dev)
-                ops.conv_c1_fwd(x.view(N, D, H, W), sd[op.w], bias, out, dims=dims, stats=stats, stats_reps=STATS_REPS)
+                if dtype == torch.bfloat16:
+                    xpad = torch.empty(N, D, H, W, 16, dtype=dtype, device=dev)
+                    ops.planar_to_cl(x, xpad, cpad=16)
+                    S.xpad = xpad
+                    wp = self._pack(op, L.PACK_CONV_FWD, dtype, sd)
+                    ops.conv_fwd([Lazy(xpad)], wp, bias, op.cout, out, grid=(N,) + gd, in_dims=gd, ksize=3, stride=1, dims=dims,
+                                 stats=stats, stats_reps=STATS_REPS)
+                else:
+                    ops.conv_c1_fwd(x.view(N, D, H, W), sd[op.w], bias, out, dims=dims, stats=stats, stats_reps=STATS_REPS)
             else:
                 srcs = [vals[s] for s in op.srcs]
                 sd_, sh_, sw_ = vdims[op.srcs[0]]
@@ -404,8 +415,13 @@ class Executor:
                     ops.conv_fwd([g], wp, None, 1, dx, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=dims,
                                  out_planar=True, out_f32=True)
                 if need_wgrad:
-                    ops.conv_c1_bwd(gt, sd[op.w], S.x.view(N, D, H, W), dims=dims, dx=None,
-                                    dw=gr[op.w], db=gr[op.b] if op.b else None)
+                    if S.xpad is not None:
+                        taps = 3 ** dims
+                        ops.wgrad([Lazy(S.xpad)], g, gr[op.w], (1, taps, taps), grid=(N, D, H, W), in_dims=(D, H, W),
+                                  ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=1)
+                    else:
+                        ops.conv_c1_bwd(gt, sd[op.w], S.x.view(N, D, H, W), dims=dims, dx=None,
+                                        dw=gr[op.w], db=gr[op.b] if op.b else None)
                 return
             srcs = [S.vals[s] for s in op.srcs]
             sd_, sh_, sw_ = S.dims[op.srcs[0]]
