@@ -79,6 +79,7 @@ class Executor:
         self._packed = {}          # dtype -> {bufs, table, ...}: packed weights + chap_pack_multi entry table
         self._ident = {}           # C -> (ones, zeros) for InstanceNorm (no affine)
         self._sides = {}           # parent stream -> forked stream for the second decoder
+        self._capture_sides = {}   # same, for use inside a graph capture (registered by the owner of the capture)
         self.has_inorm = any(op.inorm for op in program.ops)
 
     # ---------------------------------------------------------------- parameters
@@ -90,9 +91,10 @@ class Executor:
         branch on its own stream may both be inside this executor).  Eager mode only: a second level of
         fork/join inside a captured HIP graph crashes hipStreamEndCapture on ROCm 7.2, so under capture the
         decoders run back to back (the pass-B / VAT fork of ChapStep is the one level that is captured)."""
-        if torch.cuda.is_current_stream_capturing():
-            return None
         key = parent.cuda_stream
+        if torch.cuda.is_current_stream_capturing():
+            # only a stream that the caller forked from the capture's ORIGIN stream beforehand (ChapStep does, flat)
+            return self._capture_sides.get(key)
         st = self._sides.get(key)
         if st is None:
             if len(self._sides) >= 8:

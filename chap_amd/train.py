@@ -135,6 +135,12 @@ class ChapStep:
         self.grad2 = self.grad_both[n:]
         self.concurrent = bool(a.get("concurrent", True))
         self._side = torch.cuda.Stream(device=dev) if self.concurrent else None
+        # Decoder-level concurrency inside a captured graph.  On ROCm 7.2 a captured stream may fork/join with the
+        # capture's ORIGIN stream any number of times, but an event dependency between two forked streams crashes
+        # hipStreamEndCapture.  So the long chain of the iteration (the VAT branch: K+1 forward/backward pairs)
+        # stays on the origin stream, where the executor may fork its second decoder, and the short one (pass B)
+        # goes to the side stream with its decoders back to back.
+        self._d2 = torch.cuda.Stream(device=dev) if self.concurrent else None
 
     # ------------------------------------------------------------------ host-side schedule values
     def prepare(self, box_yx=None):
@@ -176,6 +182,11 @@ class ChapStep:
         lab_a, lab_b = label_batch[:lsub], label_batch[lsub:lbs]
         uimg_ab = volume_batch[lbs:]
 
+        main = torch.cuda.current_stream()
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self.concurrent and capturing:
+            self._d2.wait_stream(main)                           # enters the capture from the origin stream
+            model._exec._capture_sides = {main.cuda_stream: self._d2}
         # ---- pass A: pseudo labels from both decoders (no grad), train_ours_2D.py:314-330
         with torch.no_grad():
             pre_ab1, pre_ab2 = model(uimg_ab, drop_masks=inject.get("drop_A"))
@@ -194,40 +205,45 @@ class ChapStep:
             ops.box_mix(img_b, uimg_b, net_input_mix[:lsub], self.box)       # img_b*mask + uimg_b*(1-mask)
             ops.box_mix(uimg_a, img_a, net_input_mix[lsub:], self.box)       # uimg_a*mask + img_a*(1-mask)
 
-        # ---- the VAT branch (:368-375) depends only on pass A: it runs on a side stream beside pass B and
-        #      accumulates its parameter gradients into the second bucket
-        main = torch.cuda.current_stream()
+        # ---- pass B + the four mix_loss terms (:339-351)
+        def pass_b():
+            out_mix1, out_mix2 = model(net_input_mix, drop_masks=inject.get("drop_B"))
+            d1, d2 = torch.empty_like(out_mix1), torch.empty_like(out_mix2)
+            terms = (  # (logits, dlogits, img_l, patch_l, unlab)
+                (out_mix1[lsub:], d1[lsub:], plab_a2, lab_a, True),      # mix_loss1: out_unl1
+                (out_mix2[lsub:], d2[lsub:], plab_a1, lab_a, True),      # mix_loss2: out_unl2
+                (out_mix1[:lsub], d1[:lsub], lab_b, plab_b2, False),     # mix_loss3: out_l1
+                (out_mix2[:lsub], d2[:lsub], lab_b, plab_b1, False),     # mix_loss4: out_l2
+            )
+            losses = []
+            for lg, dl, img_l, patch_l, unlab in terms:
+                iw, pw = (0.5, 1.0) if unlab else (1.0, 0.5)            # l_weight=1.0, u_weight=0.5 (:198-203)
+                loss3, acc = ops.mix_loss_fwd(lg, img_l, patch_l, loss_mask, iw, pw)
+                ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, iw, pw, acc, dl)
+                losses.append(loss3)
+            torch.autograd.backward([out_mix1, out_mix2], [d1, d2])
+            return losses
+
+        # ---- the VAT branch (:368-375) depends only on pass A: it and pass B run side by side on two streams and
+        #      accumulate their parameter gradients into separate buckets (VAT: the second one)
         vat_loss = None
         if a["adv_noise"]:
             diff_mask = ops.diff_mask(pseudo_outputs1, pseudo_outputs2, knowledge, 4, a["topk1"])
-            if self.concurrent:
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    vat_loss = self.adv_loss(model, volume_batch, outputs_soft1, outputs_soft2, diff_mask, a["adv_losstype"],
-                                             weight_dev=self.cw_dev, inject=inject, grad_buffer=self.grad2)
-
-        # ---- pass B + the four mix_loss terms (:339-351)
-        out_mix1, out_mix2 = model(net_input_mix, drop_masks=inject.get("drop_B"))
-        d1, d2 = torch.empty_like(out_mix1), torch.empty_like(out_mix2)
-        terms = (  # (logits, dlogits, img_l, patch_l, unlab)
-            (out_mix1[lsub:], d1[lsub:], plab_a2, lab_a, True),      # mix_loss1: out_unl1
-            (out_mix2[lsub:], d2[lsub:], plab_a1, lab_a, True),      # mix_loss2: out_unl2
-            (out_mix1[:lsub], d1[:lsub], lab_b, plab_b2, False),     # mix_loss3: out_l1
-            (out_mix2[:lsub], d2[:lsub], lab_b, plab_b1, False),     # mix_loss4: out_l2
-        )
-        losses = []
-        for lg, dl, img_l, patch_l, unlab in terms:
-            iw, pw = (0.5, 1.0) if unlab else (1.0, 0.5)            # l_weight=1.0, u_weight=0.5 (:198-203)
-            loss3, acc = ops.mix_loss_fwd(lg, img_l, patch_l, loss_mask, iw, pw)
-            ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, iw, pw, acc, dl)
-            losses.append(loss3)
-        torch.autograd.backward([out_mix1, out_mix2], [d1, d2])
-
-        if a["adv_noise"] and not self.concurrent:
+        if self.concurrent and a["adv_noise"]:
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                losses = pass_b()
             vat_loss = self.adv_loss(model, volume_batch, outputs_soft1, outputs_soft2, diff_mask, a["adv_losstype"],
                                      weight_dev=self.cw_dev, inject=inject, grad_buffer=self.grad2)
-        if self.concurrent and a["adv_noise"]:
             main.wait_stream(self._side)
+        else:
+            losses = pass_b()
+            if a["adv_noise"]:
+                vat_loss = self.adv_loss(model, volume_batch, outputs_soft1, outputs_soft2, diff_mask, a["adv_losstype"],
+                                         weight_dev=self.cw_dev, inject=inject, grad_buffer=self.grad2)
+        if self.concurrent and capturing:
+            main.wait_stream(self._d2)
+            model._exec._capture_sides = {}
         if vat_loss is None:
             vat_loss = torch.zeros(1, dtype=torch.float32, device=volume_batch.device)
         if update:
