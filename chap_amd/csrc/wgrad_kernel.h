@@ -168,6 +168,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
         }
     };
 
+    // bf16 MFMA fragment offsets (elements), once per thread: lane part + (tap, 16-channel group) part of each pair
+    int a_off[MAXP], b_off = 0;
+    {
+        const int q = lane & 15, qq = q >> 2, pp = q & 3;
+        const int rowl = g >> 1, xb = 8 * (g & 1);
+        b_off = (rowl * G::TW + xb + qq) * PSB + 4 * pp;
+#pragma unroll
+        for (int i = 0; i < MAXP; ++i) {
+            const int pair = wave + 4 * i < PAIRS ? wave + 4 * i : 0;
+            const int tap = pair / KCT, kct = pair % KCT;
+            const int dx = tap % KS, dy = (tap / KS) % KS, dz = tap / (KS * KS);
+            a_off[i] = ((dz * G::HH + rowl * ST + dy) * G::HW + (xb + qq) * ST + dx) * PS + kct * 16 + 4 * pp;
+        }
+    }
     int n = 0, z0 = 0, y0 = 0, x0 = 0;
     if (my_tiles > 0) issue(split, n, z0, y0, x0);
     __syncthreads();                                            // affine caches visible
@@ -187,25 +201,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
 #pragma unroll 1
         for (int kc = 0; kc < NKCH; ++kc) {
             if constexpr (sizeof(T) == 2) {
-                // lane group g covers pixels 8g..8g+7 of the 32-pixel chunk: row = 2*kc + (g>>1), x = 8*(g&1) + 0..7
-                const int q = lane & 15, qq = q >> 2, pp = q & 3;      // this lane supplies pixel +qq, channels 4*pp..
-                const int row = 2 * kc + (g >> 1), xb = 8 * (g & 1);
+                // lane group g covers pixels 8g..8g+7 of the 32-pixel chunk: row = 2*kc + (g>>1), x = 8*(g&1) + 0..7;
+                // this lane supplies pixel +qq, channels 4*pp.. (offsets precomputed once per thread: a_off / b_off)
                 uint4 bf[NTB];
 #pragma unroll
                 for (int t = 0; t < NTB; ++t) {
-                    const bf16_t* bp = (const bf16_t*)btile + (row * G::TW + xb + qq) * PSB + t * 16 + 4 * pp;
+                    const bf16_t* bp = (const bf16_t*)btile + b_off + kc * (2 * G::TW * PSB) + t * 16;
                     const s16x4 lo = lds_tr16(bp), hi = lds_tr16(bp + 4 * PSB);
                     bf[t] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
                 }
+                // software-pipelined over the (tap, 16-row) pairs of this wave: the A fragment of pair i+1 is
+                // requested before the MFMAs of pair i (one wave per SIMD: nothing else hides the LDS latency)
+                const bf16_t* abase = (const bf16_t*)halo + kc * (2 * ST * G::HW * PS);
+                s16x4 lo = lds_tr16(abase + a_off[0]), hi = lds_tr16(abase + a_off[0] + 4 * ST * PS);
 #pragma unroll
                 for (int i = 0; i < MAXP; ++i) {
-                    const int pair = wave + 4 * i;
-                    if (pair < PAIRS) {
-                        const int tap = pair / KCT, kct = pair % KCT;
-                        const int dx = tap % KS, dy = (tap / KS) % KS, dz = tap / (KS * KS);
-                        const bf16_t* ap = (const bf16_t*)halo + ((dz * G::HH + row * ST + dy) * G::HW + (xb + qq) * ST + dx) * PS + kct * 16 + 4 * pp;
-                        const s16x4 lo = lds_tr16(ap), hi = lds_tr16(ap + 4 * ST * PS);
+                    if (wave + 4 * i < PAIRS) {                        // wave-uniform
                         const uint4 af = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+                        if (i + 1 < MAXP && wave + 4 * (i + 1) < PAIRS) {
+                            lo = lds_tr16(abase + a_off[i + 1 < MAXP ? i + 1 : i]);
+                            hi = lds_tr16(abase + a_off[i + 1 < MAXP ? i + 1 : i] + 4 * ST * PS);
+                        }
 #pragma unroll
                         for (int t = 0; t < NTB; ++t) mma8(acc[i][t], af, bf[t]);
                     }
