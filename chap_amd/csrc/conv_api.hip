@@ -43,6 +43,7 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     const int sd = p->dims == 3 ? p->stride : 1;
     CHAP_CHECK_ARG(p->ID == (p->stride == 1 ? p->D : p->D * sd) && p->IH == p->H * p->stride && p->IW == p->W * p->stride,
                    "chap_conv_fwd: input dims (%d,%d,%d) do not match grid (%d,%d,%d) stride %d", p->ID, p->IH, p->IW, p->D, p->H, p->W, p->stride);
+    if (p->dims == 3 && (p->src[0].keep || (p->nsrc > 1 && p->src[1].keep))) { chap_set_error("chap_conv_fwd: element keep masks are built for 2D only (3D: channel multipliers)"); return CHAP_EUNSUPPORTED; }
     if (p->out_mode == 1) CHAP_CHECK_ARG(p->out_Cn > 0 && p->out_Cn % 16 == 0 && p->Cout % p->out_Cn == 0, "chap_conv_fwd: depth-to-space needs Cn%%16==0");
     if (!p->out_planar) CHAP_CHECK_ARG(p->out_ld % 4 == 0 && p->out_coff % 4 == 0, "chap_conv_fwd: out_ld/out_coff must be multiples of 4");
     const int Ck = p->combine == 0 ? p->src[0].C + (p->nsrc > 1 ? p->src[1].C : 0) : p->src[0].C;

@@ -129,10 +129,12 @@ template <> struct frag<float> {
 //   * NO branch around a load: out-of-range units read the tile's first output pixel (always inside the
 //     input) and are zeroed at commit time.  A load inside a divergent `if` makes the compiler put an
 //     s_waitcnt vmcnt(0) in front of every one of them, which serialises the whole prefetch.
-template <typename T, int UNITS, bool ADD2> struct halo_regs {
+// KEEPM: element keep masks (nn.Dropout) are supported -- 2D only: no 3D network of the path has element dropout
+// (the V-Net uses Dropout3d = channel multipliers), and their 2 registers per unit are what the 3D bricks lack.
+template <typename T, int UNITS, bool ADD2, bool KEEPM = true> struct halo_regs {
     typename frag<T>::type raw[UNITS];
     typename frag<T>::type raw2[ADD2 ? UNITS : 1];
-    uint2 keep[UNITS];
+    uint2 keep[KEEPM ? UNITS : 1];
     unsigned ok;               // bit j: unit j is inside the input (else zero padding)
 };
 
@@ -177,7 +179,7 @@ __device__ __forceinline__ src_scalars make_scalars(const chap_src_t& s) {
 // LANESEL: the K-chunk straddles the two concatenated sources (s0.C % KC != 0), so the source is a per-thread
 // choice (64-bit lane addresses); otherwise it is wave-uniform per item and everything below stays scalar.
 template <typename T, typename G, bool D3, int ST, int KC, bool ADD2, int UNITS, bool LANESEL>
-__device__ __forceinline__ void halo_issue_impl(halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, const src_scalars& s0, const src_scalars& s1,
+__device__ __forceinline__ void halo_issue_impl(halo_regs<T, UNITS, ADD2, !D3>& R, const unit_desc<UNITS>& U, const src_scalars& s0, const src_scalars& s1,
                                                 int ID, int IH, int IW, int n, int z0, int y0, int x0, int chunk) {
     const int gz0 = z0 * G::STD - (D3 ? G::PAD : 0), gy0 = y0 * ST - G::PAD, gx0 = x0 * ST - G::PAD;
     const long gp0 = (((long)n * ID + gz0) * IH + gy0) * IW + gx0;           // halo origin (may lie outside: only offsets that pass the bounds test are used)
@@ -213,6 +215,7 @@ __device__ __forceinline__ void halo_issue_impl(halo_regs<T, UNITS, ADD2>& R, co
     // value carried over from the previous item would come back as register copies behind the loads, each with
     // its own s_waitcnt -- i.e. a synchronous prefetch.
     const bool hk = second ? s1.has_keep : s0.has_keep;
+    if constexpr (!D3) {
     if (!(LANESEL ? (s0.has_keep || s1.has_keep) : hk)) {
 #pragma unroll
         for (int j = 0; j < UNITS; ++j) R.keep[j] = make_uint2(0u, 0u);
@@ -227,10 +230,11 @@ __device__ __forceinline__ void halo_issue_impl(halo_regs<T, UNITS, ADD2>& R, co
             R.keep[j] = *(const uint2*)kp;
         }
     }
+    }
 }
 
 template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int UNITS, bool ZW = false>
-__device__ __forceinline__ void halo_issue(halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, const src_scalars& s0, const src_scalars& s1,
+__device__ __forceinline__ void halo_issue(halo_regs<T, UNITS, ADD2, !D3>& R, const unit_desc<UNITS>& U, const src_scalars& s0, const src_scalars& s1,
                                            int ID, int IH, int IW, int n, int z0, int y0, int x0, int chunk, bool lanesel) {
     typedef conv_geom<KS, ST, D3, MR, ZW> G;
     if (!ADD2 && lanesel) halo_issue_impl<T, G, D3, ST, KC, ADD2, UNITS, true>(R, U, s0, s1, ID, IH, IW, n, z0, y0, x0, chunk);
@@ -294,8 +298,8 @@ __device__ __forceinline__ void lazy_transform(float v[8], const float* aff, int
     }
 }
 
-template <typename T, int KC, bool ADD2, int UNITS, bool LANESEL>
-__device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
+template <typename T, int KC, bool ADD2, int UNITS, bool LANESEL, bool KEEPM>
+__device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2, KEEPM>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
                                                  const float* aff, bool plain, int n, int chunk) {
     typedef typename frag<T>::type F;
     // no per-unit branches: a path that skips a unit would leave its prefetch load un-waited as far as the compiler
@@ -332,14 +336,14 @@ __device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2>
             a[k] *= m; b[k] *= m;
         }
     }
-    const bool anyk = LANESEL ? (s0.has_keep || s1.has_keep) : hk;
+    const bool anyk = KEEPM && (LANESEL ? (s0.has_keep || s1.has_keep) : hk);
 #pragma unroll
     for (int j = 0; j < UNITS; ++j) {
         float v[8];
         frag<T>::unpack(R.raw[j], v);
         affine_act8(v, a, b, se);
         if (anyk) {
-            uint2 kp = R.keep[j];
+            uint2 kp = R.keep[KEEPM ? j : 0];
             if (LANESEL) { kp.x = hk ? kp.x : 0x01010101u; kp.y = hk ? kp.y : 0x01010101u; }
             keep8(v, kp, (LANESEL && !hk) ? 1.f : ks);
         }
@@ -354,11 +358,11 @@ __device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2>
     }
 }
 
-template <typename T, int KC, bool ADD2, int UNITS>
-__device__ __forceinline__ void halo_commit(const halo_regs<T, UNITS, ADD2>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
+template <typename T, int KC, bool ADD2, int UNITS, bool KEEPM>
+__device__ __forceinline__ void halo_commit(const halo_regs<T, UNITS, ADD2, KEEPM>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
                                             const float* aff, bool plain, int n, int chunk, bool lanesel) {
-    if (!ADD2 && lanesel) halo_commit_impl<T, KC, ADD2, UNITS, true>(R, U, halo, s0, s1, aff, plain, n, chunk);
-    else halo_commit_impl<T, KC, ADD2, UNITS, false>(R, U, halo, s0, s1, aff, plain, n, chunk);
+    if (!ADD2 && lanesel) halo_commit_impl<T, KC, ADD2, UNITS, true, KEEPM>(R, U, halo, s0, s1, aff, plain, n, chunk);
+    else halo_commit_impl<T, KC, ADD2, UNITS, false, KEEPM>(R, U, halo, s0, s1, aff, plain, n, chunk);
 }
 
 // tile index -> (n, z0, y0, x0); tiles_z = number of tile layers along D (D itself when the tile is one plane)
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     // bias) is issued before the first dependent LDS store, so that the block pays ONE memory round trip before
     // its first tile instead of four in a row (a block only owns a handful of tiles: this is a large part of
     // its life).  No load sits inside a divergent branch (see halo_issue).
-    halo_regs<T, UNITS, ADD2> R;
+    halo_regs<T, UNITS, ADD2, !D3> R;
     // tile walk: this block visits tiles t_begin + bix + k*bpx; the (x, y, z, n) tile coordinates advance by the
     // mixed-radix digits of bpx with carries (scalar adds/compares instead of three divisions per tile)
     int ntx = 0, nty = 0, ntz = 0, nn = 0;                      // tile coordinates of the item being prefetched
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     CHAP_STAMP_P(1);
     __syncthreads();                                            // affine cache (+ resident weights) visible
     CHAP_STAMP_P(2);
-    if (nitems > 0) { halo_commit<T, KC, ADD2, UNITS>(R, U, halo0, s0, s1, aff, plain, nn, 0, lanesel); wstage_commit(0); }
+    if (nitems > 0) { halo_commit<T, KC, ADD2, UNITS, !D3>(R, U, halo0, s0, s1, aff, plain, nn, 0, lanesel); wstage_commit(0); }
     __syncthreads();
     CHAP_STAMP_P(3);
 
@@ -619,12 +623,14 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         const T* wc_l = wlds + ((long)(WLDS ? chunk : (int)(it & 1)) * STEPS * NT * 64 + lane) * 8;
         // software-pipelined: the fragments of step s+1 are requested before the MFMAs of step s are issued, so
         // the LDS (or L2) latency hides behind MR*NT MFMAs instead of preceding every one of them
-        auto load_step = [&](int step, F (&wf)[NT], F (&xf)[MR]) {
+        auto load_w = [&](int step, F (&wf)[NT]) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 if (WLDS || WST) wf[t] = frag<T>::load(wc_l + ((long)step * NT + t) * 512);
                 else wf[t] = frag<T>::load(wc_g + (long)step * wstep + (nt0 + t < ntiles_total ? t : 0) * 512);   // clamped: those channels are never stored
             }
+        };
+        auto load_x = [&](int step, F (&xf)[MR]) {
             const int xo = xoff[step];
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
@@ -632,18 +638,23 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
                 else xf[m] = xo >= 0 ? frag<T>::load(cur + xo + m * (ST * G::HW * PS)) : frag<T>::zero();
             }
         };
-        F wfa[NT], xfa[MR], wfb[NT], xfb[MR];
+        // pixel fragments (LDS) one step ahead; weight fragments one step ahead from LDS, TWO steps ahead when they
+        // stream from L2 (one step of MR*NT MFMAs does not cover an L2 round trip)
+        constexpr int WD = (WLDS || WST) ? 2 : 3;               // ring depth of the weight fragments
+        F wq[WD][NT], xq[2][MR];
         constexpr int NSTEP = (CHAP_ABLATE & 2) ? 0 : STEPS;
-        if (NSTEP > 0) load_step(0, wfa, xfa);
+        if (NSTEP > 0) { load_w(0, wq[0]); load_x(0, xq[0]); }
+        if (WD == 3 && NSTEP > 1) load_w(1, wq[1]);
 #pragma unroll
         for (int step = 0; step < NSTEP; ++step) {
-            if (step + 1 < NSTEP) { if (step & 1) load_step(step + 1, wfa, xfa); else load_step(step + 1, wfb, xfb); }
+            if (step + WD - 1 < NSTEP) load_w(step + WD - 1, wq[(step + WD - 1) % WD]);
+            if (step + 1 < NSTEP) load_x(step + 1, xq[(step + 1) & 1]);
 #pragma unroll
             for (int m = 0; m < MR; ++m)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const F& w = (step & 1) ? wfb[t] : wfa[t];
-                    const F& x = (step & 1) ? xfb[m] : xfa[m];
+                    const F& w = wq[step % WD][t];
+                    const F& x = xq[step & 1][m];
                     if (CHAP_ABLATE & 1) { float kx[8], kw[8]; frag<T>::unpack(x, kx); frag<T>::unpack(w, kw); asm volatile("" :: "v"(kx[0]), "v"(kx[7]), "v"(kw[0]), "v"(kw[7])); } else mma8(acc[m][t], w, x);
                 }
         }
@@ -715,7 +726,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         //  `if (has_next) commit` the compiler must assume the prefetch registers still have loads in flight at the
         //  top of the next item and waits for every outstanding store before it issues the new loads)
         if (!has_next) break;
-        halo_commit<T, KC, ADD2, UNITS>(R, U, nxt, s0, s1, aff, plain, nn, nchunk, lanesel);
+        halo_commit<T, KC, ADD2, UNITS, !D3>(R, U, nxt, s0, s1, aff, plain, nn, nchunk, lanesel);
         wstage_commit((int)((it + 1) & 1));
         chunk = nchunk == nchunks ? 0 : nchunk;
         CHAP_STAMP(4);

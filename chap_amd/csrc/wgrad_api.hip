@@ -91,6 +91,7 @@ extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     const int sd = p->dims == 3 ? p->stride : 1;
     CHAP_CHECK_ARG(p->ID == (p->stride == 1 ? p->D : p->D * sd) && p->IH == p->H * p->stride && p->IW == p->W * p->stride,
                    "chap_wgrad: A dims (%d,%d,%d) do not match grid (%d,%d,%d) stride %d", p->ID, p->IH, p->IW, p->D, p->H, p->W, p->stride);
+    if (p->dims == 3 && (p->a[0].keep || (p->na > 1 && p->a[1].keep))) { chap_set_error("chap_wgrad: element keep masks on the A operand are built for 2D only"); return CHAP_EUNSUPPORTED; }
     float* ws = (float*)p->ws;
     float* ws_db = p->db ? ws + (size_t)q.nsplit * (q.slab / sizeof(float)) : nullptr;
     hipStream_t s = (hipStream_t)stream;

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
     for (int j = 0; j < 8; ++j) dbsum[j] = 0.f;
     const bool want_db = ws_db != nullptr && chunk == 0;
 
-    halo_regs<T, UNITS, ADD2> R;
+    halo_regs<T, UNITS, ADD2, !D3> R;
     F braw[BUNITS]; uint2 bkeep[BUNITS]; unsigned bok = 0;
     f32x2 ba[4], bb2[4];                                        // scale/shift of this thread's 8 B channels
     const int cbB_safe = bchan_ok ? cbB : 0;
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
         }
     };
     auto commit = [&](T* halo, T* bt, int n) {
-        halo_commit<T, KC, ADD2, UNITS>(R, U, halo, s0, s1, aff, plainA, n, chunk, lanesel);
+        halo_commit<T, KC, ADD2, UNITS, !D3>(R, U, halo, s0, s1, aff, plainA, n, chunk, lanesel);
         f32x2 a[4], b[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { a[k] = ba[k]; b[k] = bb2[k]; }
