@@ -345,9 +345,82 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const chap_upsample_par
         st8((T*)P.out + op * P.out_ld + P.out_coff + c8, acc);
     }
 }
+// Cell form (used whenever every interpolated axis has >= 2 input samples): one thread owns one input CELL
+// (the interval [i, i+1] on each interpolated axis) and 8 channels, loads and transforms (lazy activation) its
+// 4 / 8 corner samples ONCE and writes every output sample whose source coordinate falls into the cell (2 per
+// axis on average for x2).  The per-output form above re-loads and re-transforms the corners for each output:
+// 8x the loads and VALU work in 3D.  Same weights, same summation order as the per-output form.
+__device__ __forceinline__ int up_axis_outputs(int i, int in, int out, bool hp, int o_[5], float w_[5]) {
+    int n = 0;
+    for (int o = max(0, 2 * i - 1); o <= min(out - 1, 2 * i + 3); ++o) {      // 2i+3: only the clamped last output of the last cell
+        int i0, i1; float w1;
+        ac_coord(o, in, out, i0, i1, w1, hp);
+        if (i0 > in - 2) { i0 = in - 2; w1 = 1.f; }             // source clamped to the last sample: corner 1 with weight 1
+        if (i0 == i) { o_[n] = o; w_[n] = w1; ++n; }
+    }
+    return n;
+}
+template <typename T, bool D3>
+__global__ __launch_bounds__(256) void upsample2x_cell_kernel(const chap_upsample_params P) {
+    const int C8 = P.r.C / 8;
+    const int OD = D3 ? 2 * P.D : P.D, OH = 2 * P.H, OW = 2 * P.W;
+    const int CD = D3 ? P.D - 1 : P.D, CH = P.H - 1, CW = P.W - 1;       // cells per axis
+    const long total = (long)P.N * CD * CH * CW * C8;
+    const bool hp = P.half_pixel != 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const u32 ui = (u32)i;
+        const int c8 = (int)(ui % (u32)C8) * 8; u32 r = ui / (u32)C8;
+        const int cx = (int)(r % (u32)CW); r /= (u32)CW;
+        const int cy = (int)(r % (u32)CH); r /= (u32)CH;
+        const int cz = (int)(r % (u32)CD); const int n = (int)(r / (u32)CD);
+        float v[D3 ? 2 : 1][2][2][8];
+#pragma unroll
+        for (int kz = 0; kz < (D3 ? 2 : 1); ++kz)
+#pragma unroll
+            for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 2; ++kx)
+                    src_load8<T>(P.r, n, (((long)n * P.D + cz + kz) * P.H + cy + ky) * P.W + cx + kx, c8, v[kz][ky][kx]);
+        int oz_[5], oy_[5], ox_[5]; float wz_[5], wy_[5], wx_[5];
+        int nz = 1; oz_[0] = cz; wz_[0] = 0.f;
+        if (D3) nz = up_axis_outputs(cz, P.D, OD, hp, oz_, wz_);
+        const int ny = up_axis_outputs(cy, P.H, OH, hp, oy_, wy_);
+        const int nx = up_axis_outputs(cx, P.W, OW, hp, ox_, wx_);
+        for (int a = 0; a < nz; ++a)
+            for (int b = 0; b < ny; ++b)
+                for (int c = 0; c < nx; ++c) {
+                    const float wz = wz_[a], wy = wy_[b], wx = wx_[c];
+                    float acc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+                    for (int kz = 0; kz < (D3 ? 2 : 1); ++kz)
+#pragma unroll
+                        for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+                            for (int kx = 0; kx < 2; ++kx) {
+                                const float w = (kz ? wz : 1.f - wz) * (ky ? wy : 1.f - wy) * (kx ? wx : 1.f - wx);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, v[kz][ky][kx][j], acc[j]);
+                            }
+                    const long op = (((long)n * OD + oz_[a]) * OH + oy_[b]) * OW + ox_[c];
+                    st8((T*)P.out + op * P.out_ld + P.out_coff + c8, acc);
+                }
+    }
+}
 extern "C" int chap_upsample2x(const chap_upsample_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->r.ptr && p->out && p->r.C % 8 == 0, "chap_upsample2x: bad argument");
     CHAP_CHECK_ARG(p->out_ld % 8 == 0 && p->out_coff % 8 == 0, "chap_upsample2x: out_ld/out_coff must be multiples of 8");
+    const bool d3 = p->dims == 3;
+    if (p->H >= 2 && p->W >= 2 && (!d3 || p->D >= 2)) {
+        const long cells = (long)p->N * (d3 ? p->D - 1 : p->D) * (p->H - 1) * (p->W - 1) * (p->r.C / 8);
+        const int blocks = (int)(cdiv(cells, 256) < 16384 ? cdiv(cells, 256) : 16384);
+        hipStream_t s = (hipStream_t)stream;
+        if (p->dtype == CHAP_BF16) { if (d3) hipLaunchKernelGGL((upsample2x_cell_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, s, *p); else hipLaunchKernelGGL((upsample2x_cell_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, s, *p); }
+        else { if (d3) hipLaunchKernelGGL((upsample2x_cell_kernel<float, true>), dim3(blocks), dim3(256), 0, s, *p); else hipLaunchKernelGGL((upsample2x_cell_kernel<float, false>), dim3(blocks), dim3(256), 0, s, *p); }
+        CHAP_LAUNCH_CHECK("chap_upsample2x");
+        return CHAP_OK;
+    }
     const long total = (long)p->N * (p->dims == 3 ? 2 * p->D : p->D) * 2 * p->H * 2 * p->W * (p->r.C / 8);
     const int blocks = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(upsample2x_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
@@ -359,6 +432,17 @@ extern "C" int chap_upsample2x(const chap_upsample_params* p, void* stream) {
 // Adjoint: each coarse pixel gathers from the fine pixels whose stencil touches it (no atomics).
 // Along one axis, fine index o touches coarse i iff i0(o) == i or i1(o) == i; with scale
 // (in-1)/(out-1) < 1/2 only o in [2i-2, 2i+2] can qualify, so a 5-wide window per axis suffices.
+// weight with which fine sample o feeds coarse sample i along one axis (0 when its stencil does not touch i)
+__device__ __forceinline__ int up_axis_adjoint(int i, int in, int out, int o_[5], float w_[5]) {
+    int n = 0;
+    for (int o = max(0, 2 * i - 2); o <= min(out - 1, 2 * i + 2); ++o) {
+        int a0, a1; float w1;
+        ac_coord(o, in, out, a0, a1, w1);
+        const float w = (a0 == i ? 1.f - w1 : 0.f) + (a1 == i ? w1 : 0.f);
+        if (w != 0.f) { o_[n] = o; w_[n] = w; ++n; }
+    }
+    return n;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const chap_upsample_bwd_params P) {
     const int C8 = P.C / 8;
@@ -374,31 +458,22 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const chap_upsample
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        const int zlo = P.dims == 3 ? max(0, 2 * z - 2) : z, zhi = P.dims == 3 ? min(OD - 1, 2 * z + 2) : z;
-        for (int oz = zlo; oz <= zhi; ++oz) {
-            float wz = 1.f;
-            if (P.dims == 3) {
-                int a0, a1; float w1; ac_coord(oz, P.D, OD, a0, a1, w1);
-                wz = (a0 == z ? 1.f - w1 : 0.f) + (a1 == z ? w1 : 0.f);
-                if (wz == 0.f) continue;
-            }
-            for (int oy = max(0, 2 * y - 2); oy <= min(OH - 1, 2 * y + 2); ++oy) {
-                int b0, b1; float v1; ac_coord(oy, P.H, OH, b0, b1, v1);
-                const float wy = (b0 == y ? 1.f - v1 : 0.f) + (b1 == y ? v1 : 0.f);
-                if (wy == 0.f) continue;
-                for (int ox = max(0, 2 * x - 2); ox <= min(OW - 1, 2 * x + 2); ++ox) {
-                    int c0, c1; float u1; ac_coord(ox, P.W, OW, c0, c1, u1);
-                    const float wx = (c0 == x ? 1.f - u1 : 0.f) + (c1 == x ? u1 : 0.f);
-                    if (wx == 0.f) continue;
-                    const long fp = (((long)n * OD + oz) * OH + oy) * OW + ox;
+        // per-axis contributor lists first (the nested form evaluated the source coordinate 5*5*5 times per thread)
+        int oz_[5], oy_[5], ox_[5]; float wz_[5], wy_[5], wx_[5];
+        int nz = 1; oz_[0] = z; wz_[0] = 1.f;
+        if (P.dims == 3) nz = up_axis_adjoint(z, P.D, OD, oz_, wz_);
+        const int ny = up_axis_adjoint(y, P.H, OH, oy_, wy_);
+        const int nx = up_axis_adjoint(x, P.W, OW, ox_, wx_);
+        for (int a = 0; a < nz; ++a)
+            for (int b = 0; b < ny; ++b)
+                for (int c = 0; c < nx; ++c) {
+                    const long fp = (((long)n * OD + oz_[a]) * OH + oy_[b]) * OW + ox_[c];
                     float v[8];
                     ld8(g + fp * P.g_ld + P.g_coff + c8, v);
-                    const float w = wz * wy * wx;
+                    const float w = wz_[a] * wy_[b] * wx_[c];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, v[j], acc[j]);
                 }
-            }
-        }
         const long cp = (((long)n * P.D + z) * P.H + y) * P.W + x;
         st8((T*)P.out + cp * P.C + c8, acc);
     }
