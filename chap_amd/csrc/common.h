@@ -47,7 +47,14 @@ __device__ __forceinline__ void st8(float* p, const float v[8]) {
     *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
     *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
-__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+typedef __bf16 bf16x2_native __attribute__((ext_vector_type(2)));
+typedef float f32x2_native __attribute__((ext_vector_type(2)));
+// two floats -> one dword of bf16 with ONE v_cvt_pk_bf16_f32 (RNE); converting them one by one costs a cvt each plus
+// and/shift/or to merge, and the staging / store paths are VALU-issue bound
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    const f32x2_native v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_native));
+}
 __device__ __forceinline__ void st8(bf16_t* p, const float v[8]) {
     *(uint4*)p = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
 }

@@ -178,7 +178,8 @@ __device__ __forceinline__ src_scalars make_scalars(const chap_src_t& s) {
 
 // LANESEL: the K-chunk straddles the two concatenated sources (s0.C % KC != 0), so the source is a per-thread
 // choice (64-bit lane addresses); otherwise it is wave-uniform per item and everything below stays scalar.
-template <typename T, typename G, bool D3, int ST, int KC, bool ADD2, int UNITS, bool LANESEL>
+// ONE: the launch has exactly one source (most layers): every "which source" select and all of s1 disappear.
+template <typename T, typename G, bool D3, int ST, int KC, bool ADD2, int UNITS, bool LANESEL, bool ONE>
 __device__ __forceinline__ void halo_issue_impl(halo_regs<T, UNITS, ADD2, !D3>& R, const unit_desc<UNITS>& U, const src_scalars& s0, const src_scalars& s1,
                                                 int ID, int IH, int IW, int n, int z0, int y0, int x0, int chunk) {
     const int gz0 = z0 * G::STD - (D3 ? G::PAD : 0), gy0 = y0 * ST - G::PAD, gx0 = x0 * ST - G::PAD;
@@ -188,7 +189,7 @@ __device__ __forceinline__ void halo_issue_impl(halo_regs<T, UNITS, ADD2, !D3>& 
     const unsigned PB = ((unsigned)(512 - hiz) << 20) | ((unsigned)(512 - hiy) << 10) | (unsigned)(512 - hix);
     const unsigned rsafe = ((D3 ? G::PAD : 0) * IH + G::PAD) * IW + G::PAD;
     const int cb = chunk * KC;
-    const bool second = ADD2 ? false : (LANESEL ? (cb + U.c8 >= s0.C) : (cb >= s0.C));
+    const bool second = (ADD2 || ONE) ? false : (LANESEL ? (cb + U.c8 >= s0.C) : (cb >= s0.C));
     const int cs = second ? cb - s0.C : cb;                      // first channel of the chunk inside the source (can be < 0 for LANESEL lanes of s1: + c8 >= 0)
     const int ld = second ? s1.ld : s0.ld;
     const char* base = (const char*)(second ? s1.ptr : s0.ptr) + (gp0 * ld + (second ? s1.coff : s0.coff) + cs) * (long)sizeof(T);
@@ -233,12 +234,13 @@ __device__ __forceinline__ void halo_issue_impl(halo_regs<T, UNITS, ADD2, !D3>& 
     }
 }
 
-template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int UNITS, bool ZW = false>
+template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int UNITS, bool ZW = false, bool ONE = false>
 __device__ __forceinline__ void halo_issue(halo_regs<T, UNITS, ADD2, !D3>& R, const unit_desc<UNITS>& U, const src_scalars& s0, const src_scalars& s1,
                                            int ID, int IH, int IW, int n, int z0, int y0, int x0, int chunk, bool lanesel) {
     typedef conv_geom<KS, ST, D3, MR, ZW> G;
-    if (!ADD2 && lanesel) halo_issue_impl<T, G, D3, ST, KC, ADD2, UNITS, true>(R, U, s0, s1, ID, IH, IW, n, z0, y0, x0, chunk);
-    else halo_issue_impl<T, G, D3, ST, KC, ADD2, UNITS, false>(R, U, s0, s1, ID, IH, IW, n, z0, y0, x0, chunk);
+    if (ONE) halo_issue_impl<T, G, D3, ST, KC, ADD2, UNITS, false, true>(R, U, s0, s0, ID, IH, IW, n, z0, y0, x0, chunk);
+    else if (!ADD2 && lanesel) halo_issue_impl<T, G, D3, ST, KC, ADD2, UNITS, true, false>(R, U, s0, s1, ID, IH, IW, n, z0, y0, x0, chunk);
+    else halo_issue_impl<T, G, D3, ST, KC, ADD2, UNITS, false, false>(R, U, s0, s1, ID, IH, IW, n, z0, y0, x0, chunk);
 }
 
 // affine cache layout in LDS: [src][scale | shift][CONV_MAX_AFFINE_C/2] (identity when a source has none).
@@ -249,10 +251,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // scale/shift of the 8 channels a thread stages, held in registers (per K-chunk; they do not depend on the tile)
 template <bool ADD2> struct aff_regs { f32x2 a[4], b[4], a2[ADD2 ? 4 : 1], b2[ADD2 ? 4 : 1]; };
 
-template <int KC, bool ADD2>
+template <int KC, bool ADD2, bool ONE = false>
 __device__ __forceinline__ void load_aff(aff_regs<ADD2>& A, const float* aff, int c8, int C0, int chunk, bool lanesel) {
     const int cb = chunk * KC;
-    const bool second = ADD2 ? false : (lanesel ? (cb + c8 >= C0) : (cb >= C0));
+    const bool second = (ADD2 || ONE) ? false : (lanesel ? (cb + c8 >= C0) : (cb >= C0));
     const float* af = aff + (second ? CONV_MAX_AFFINE_C + cb - C0 : cb) + c8;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { A.a[k] = *(const f32x2*)(af + 2 * k); A.b[k] = *(const f32x2*)(af + CONV_MAX_AFFINE_C / 2 + 2 * k); }
@@ -298,7 +300,7 @@ __device__ __forceinline__ void lazy_transform(float v[8], const float* aff, int
     }
 }
 
-template <typename T, int KC, bool ADD2, int UNITS, bool LANESEL, bool KEEPM>
+template <typename T, int KC, bool ADD2, int UNITS, bool LANESEL, bool KEEPM, bool ONE>
 __device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2, KEEPM>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
                                                  const float* aff, bool plain, int n, int chunk) {
     typedef typename frag<T>::type F;
@@ -310,14 +312,14 @@ __device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2,
         return;
     }
     const int cb = chunk * KC;
-    const bool second = ADD2 ? false : (LANESEL ? (cb + U.c8 >= s0.C) : (cb >= s0.C));
+    const bool second = (ADD2 || ONE) ? false : (LANESEL ? (cb + U.c8 >= s0.C) : (cb >= s0.C));
     const float se = second ? s1.slope_eff : s0.slope_eff;
     const bool hk = second ? s1.has_keep : s0.has_keep;
     const float ks = second ? s1.keep_scale : s0.keep_scale;
     const bool hcm = second ? s1.has_cm : s0.has_cm;
     // scale/shift of this thread's 8 channels: 4 LDS reads per item are cheaper than 16 registers held across the MFMA loop
     aff_regs<ADD2> A;
-    load_aff<KC, ADD2>(A, aff, U.c8, s0.C, chunk, LANESEL);
+    load_aff<KC, ADD2, ONE>(A, aff, U.c8, s0.C, chunk, LANESEL);
     f32x2 a[4], b[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { a[k] = A.a[k]; b[k] = A.b[k]; }
@@ -358,11 +360,12 @@ __device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2,
     }
 }
 
-template <typename T, int KC, bool ADD2, int UNITS, bool KEEPM>
+template <typename T, int KC, bool ADD2, int UNITS, bool KEEPM, bool ONE = false>
 __device__ __forceinline__ void halo_commit(const halo_regs<T, UNITS, ADD2, KEEPM>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
                                             const float* aff, bool plain, int n, int chunk, bool lanesel) {
-    if (!ADD2 && lanesel) halo_commit_impl<T, KC, ADD2, UNITS, true, KEEPM>(R, U, halo, s0, s1, aff, plain, n, chunk);
-    else halo_commit_impl<T, KC, ADD2, UNITS, false, KEEPM>(R, U, halo, s0, s1, aff, plain, n, chunk);
+    if (ONE) halo_commit_impl<T, KC, ADD2, UNITS, false, KEEPM, true>(R, U, halo, s0, s0, aff, plain, n, chunk);
+    else if (!ADD2 && lanesel) halo_commit_impl<T, KC, ADD2, UNITS, true, KEEPM, false>(R, U, halo, s0, s1, aff, plain, n, chunk);
+    else halo_commit_impl<T, KC, ADD2, UNITS, false, KEEPM, false>(R, U, halo, s0, s1, aff, plain, n, chunk);
 }
 
 // tile index -> (n, z0, y0, x0); tiles_z = number of tile layers along D (D itself when the tile is one plane)
@@ -375,7 +378,7 @@ __device__ __forceinline__ void tile_coords(long tile, int tiles_x, int tiles_y,
     x0 = (int)tx * TW; y0 = (int)ty * TH;
 }
 
-template <typename T, int KS, int ST, bool D3, int KC, int NT, int MR, bool ADD2, bool WLDS, bool ZW = false>
+template <typename T, int KS, int ST, bool D3, int KC, int NT, int MR, bool ADD2, bool WLDS, bool ZW = false, bool ONE = false>
 __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES : (KC == 16 && !D3 ? 3 : 1))) void conv_fwd_kernel(const chap_conv_params P) {
     typedef conv_geom<KS, ST, D3, MR, ZW> G;
     typedef typename frag<T>::type F;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
                        (!ADD2 && P.src[0].scale == nullptr && !P.src[0].act && P.src[0].keep == nullptr && P.src[0].chan_mul == nullptr &&
                         (P.nsrc < 2 || (P.src[1].scale == nullptr && !P.src[1].act && P.src[1].keep == nullptr && P.src[1].chan_mul == nullptr)));
     const src_scalars s0 = make_scalars(P.src[0]);
-    const src_scalars s1 = make_scalars(P.nsrc > 1 ? P.src[1] : P.src[0]);
+    const src_scalars s1 = make_scalars((!ONE && P.nsrc > 1) ? P.src[1] : P.src[0]);
 
     // XCD-aware tile walk: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous range
     // of tiles so that the halos re-read by neighbouring tiles are L2 hits.
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     // ---- one-time per thread: unit descriptors, MFMA fragment offsets ----
     unit_desc<UNITS> U;
     make_units<G, GPT, PS, UNITS>(U, P.IH, P.IW);
-    const bool lanesel = !ADD2 && P.nsrc > 1 && (P.src[0].C % KC) != 0;   // a K-chunk straddles the two concatenated sources
+    const bool lanesel = !ADD2 && !ONE && P.nsrc > 1 && (P.src[0].C % KC) != 0;   // a K-chunk straddles the two concatenated sources
     int xoff[STEPS];                                            // LDS element offset of this lane's B fragment (row m = 0), -1 = zero fragment
 #pragma unroll
     for (int step = 0; step < STEPS; ++step) {
@@ -448,13 +451,13 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         ntz = t % (unsigned)tiles_z; nn = t / (unsigned)tiles_z;
     }
     if (nitems > 0)
-        halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, ntz * G::TD, nty * G::TH, ntx * G::TW, 0, lanesel);
+        halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW, ONE>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, ntz * G::TD, nty * G::TH, ntx * G::TW, 0, lanesel);
 
     // scale/shift of both sources -> registers (CONV_MAX_AFFINE_C/2 = 512 channels per source: 2 per thread)
     float asc[2][2], ash[2][2];
     if (!plain) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < (ONE ? 1 : 2); ++s) {
             const chap_src_t& S = P.src[s < P.nsrc ? s : 0];
             const bool has = S.scale != nullptr;
 #pragma unroll
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     // ---- now the dependent LDS stores
     if (!plain) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < (ONE ? 1 : 2); ++s) {
             if (s < P.nsrc) {
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     CHAP_STAMP_P(1);
     __syncthreads();                                            // affine cache (+ resident weights) visible
     CHAP_STAMP_P(2);
-    if (nitems > 0) { halo_commit<T, KC, ADD2, UNITS, !D3>(R, U, halo0, s0, s1, aff, plain, nn, 0, lanesel); wstage_commit(0); }
+    if (nitems > 0) { halo_commit<T, KC, ADD2, UNITS, !D3, ONE>(R, U, halo0, s0, s1, aff, plain, nn, 0, lanesel); wstage_commit(0); }
     __syncthreads();
     CHAP_STAMP_P(3);
 
@@ -614,7 +617,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
                 ntz += sz + c; c = ntz >= tiles_z; ntz -= c ? tiles_z : 0;
                 nn += sn + c;
             }
-            halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, ntz * G::TD, nty * G::TH, ntx * G::TW, nchunk, lanesel);
+            halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW, ONE>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, ntz * G::TD, nty * G::TH, ntx * G::TW, nchunk, lanesel);
             wstage_issue(nchunk);
         }
         CHAP_STAMP(1);
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         //  `if (has_next) commit` the compiler must assume the prefetch registers still have loads in flight at the
         //  top of the next item and waits for every outstanding store before it issues the new loads)
         if (!has_next) break;
-        halo_commit<T, KC, ADD2, UNITS, !D3>(R, U, nxt, s0, s1, aff, plain, nn, nchunk, lanesel);
+        halo_commit<T, KC, ADD2, UNITS, !D3, ONE>(R, U, nxt, s0, s1, aff, plain, nn, nchunk, lanesel);
         wstage_commit((int)((it + 1) & 1));
         chunk = nchunk == nchunks ? 0 : nchunk;
         CHAP_STAMP(4);
