@@ -21,6 +21,18 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 
+// Sum over the 16 lanes of a DPP row (lanes 16r .. 16r+15), result in every lane: four v_add_f32 with a DPP source
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror) -- the same pairings, hence the same rounding, as an xor
+// butterfly 1-2-4-8, without the ds_bpermute + address arithmetic of __shfl_xor.
+#define CHAP_DPP_ADD(v, ctrl) (v) += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float row16_sum(float v) {
+    CHAP_DPP_ADD(v, 0xB1);      // quad_perm [1,0,3,2]
+    CHAP_DPP_ADD(v, 0x4E);      // quad_perm [2,3,0,1]
+    CHAP_DPP_ADD(v, 0x141);     // row_half_mirror
+    CHAP_DPP_ADD(v, 0x140);     // row_mirror
+    return v;
+}
+
 template <typename T> struct elem;
 template <> struct elem<float> {
     static __device__ __forceinline__ float get(float v) { return v; }

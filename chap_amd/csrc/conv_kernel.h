@@ -412,9 +412,13 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     const int nb = gridDim.x;
     const int xcd = blockIdx.x & 7, bix = blockIdx.x >> 3;
     const int bpx = (nb + 7 - xcd) >> 3;                        // blocks on this XCD group
-    const long per = (ntiles + 7) / 8;
-    const long t_begin = per * xcd, t_end = (t_begin + per < ntiles) ? t_begin + per : ntiles;
-    const long my_tiles = (t_begin + bix < t_end) ? (t_end - t_begin - bix + bpx - 1) / bpx : 0;
+    // each block owns a CONTIGUOUS run of this XCD's tiles (consecutive tiles share halo rows; the walk is +1 with carries)
+    const unsigned per = ((unsigned)ntiles + 7u) / 8u;
+    const unsigned t_lo = per * (unsigned)xcd, t_hi = min(t_lo + per, (unsigned)ntiles);
+    const unsigned range = t_hi > t_lo ? t_hi - t_lo : 0u;
+    const unsigned tq = range / (unsigned)bpx, trem = range - tq * (unsigned)bpx;
+    const unsigned t_first = t_lo + (unsigned)bix * tq + min((unsigned)bix, trem);
+    const long my_tiles = (long)(tq + ((unsigned)bix < trem ? 1u : 0u));
     const long nitems = my_tiles * nchunks;
 
     // ---- one-time per thread: unit descriptors, MFMA fragment offsets ----
@@ -436,16 +440,10 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     // its first tile instead of four in a row (a block only owns a handful of tiles: this is a large part of
     // its life).  No load sits inside a divergent branch (see halo_issue).
     halo_regs<T, UNITS, ADD2, !D3> R;
-    // tile walk: this block visits tiles t_begin + bix + k*bpx; the (x, y, z, n) tile coordinates advance by the
-    // mixed-radix digits of bpx with carries (scalar adds/compares instead of three divisions per tile)
+    // tile walk: tiles t_first, t_first + 1, ...: the (x, y, z, n) tile coordinates advance by +1 with carries
     int ntx = 0, nty = 0, ntz = 0, nn = 0;                      // tile coordinates of the item being prefetched
-    int sx, sy, sz, sn;
     {
-        unsigned r = (unsigned)bpx;
-        sx = r % (unsigned)tiles_x; r /= (unsigned)tiles_x;
-        sy = r % (unsigned)tiles_y; r /= (unsigned)tiles_y;
-        sz = r % (unsigned)tiles_z; sn = r / (unsigned)tiles_z;
-        unsigned t = (unsigned)(t_begin + bix);
+        unsigned t = t_first;
         ntx = t % (unsigned)tiles_x; t /= (unsigned)tiles_x;
         nty = t % (unsigned)tiles_y; t /= (unsigned)tiles_y;
         ntz = t % (unsigned)tiles_z; nn = t / (unsigned)tiles_z;
@@ -500,18 +498,19 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     if (WST && nitems > 0) wstage_issue(0);
     // resident weights: [chunk][step][t < NT][64 lanes][8]; first batch of 8 fragments per thread in flight now
     const long wtot = WLDS ? (long)nchunks * STEPS * NT * 64 : 0;
-    auto wload = [&](long i) -> F {
-        const long ic = i < wtot ? i : 0;                        // clamp, no branch around the load
-        const int ln = (int)(ic & 63); long r = ic >> 6;
-        int t = (int)(r % NT); r /= NT;                          // r = chunk*STEPS + step
-        t = nt0 + t < ntiles_total ? t : 0;
-        return frag<T>::load((const T*)P.wpacked + r * wstep + ((long)(nt0 + t) * 64 + ln) * 8);
+    const unsigned uwtot = (unsigned)wtot;
+    auto wload = [&](unsigned i) -> F {                          // 32-bit index math (the packed weights are far below 2 GB)
+        const unsigned ic = i < uwtot ? i : 0u;                  // clamp, no branch around the load
+        const unsigned ln = ic & 63u; unsigned r = ic >> 6;
+        unsigned t = r % (unsigned)NT; r /= (unsigned)NT;        // r = chunk*STEPS + step
+        t = nt0 + (int)t < ntiles_total ? t : 0u;
+        return frag<T>::load((const T*)((const char*)P.wpacked + (size_t)((r * (unsigned)wstep + ((unsigned)nt0 + t) * 512u + ln * 8u) * (unsigned)sizeof(T))));
     };
-    auto wkeep = [&](long i) -> bool { return i < wtot && nt0 + (int)((i >> 6) % NT) < ntiles_total; };
+    auto wkeep = [&](unsigned i) -> bool { return i < uwtot && nt0 + (int)((i >> 6) % (unsigned)NT) < ntiles_total; };
     F wf0[8];
     if (WLDS) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) wf0[k] = wload((long)threadIdx.x + 256 * k);
+        for (int k = 0; k < 8; ++k) wf0[k] = wload(threadIdx.x + 256u * k);
     }
 
     f32x4 acc[MR][NT];
@@ -545,17 +544,17 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     if (WLDS) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const long i = (long)threadIdx.x + 256 * k;
-            if (i < wtot) frag<T>::store(wlds + i * 8, wkeep(i) ? wf0[k] : frag<T>::zero());
+            const unsigned i = threadIdx.x + 256u * k;
+            if (i < uwtot) frag<T>::store(wlds + i * 8u, wkeep(i) ? wf0[k] : frag<T>::zero());
         }
-        for (long i0 = (long)threadIdx.x + 256 * 8; i0 < wtot; i0 += 256 * 8) {     // larger layers: further batches of 8
+        for (unsigned i0 = threadIdx.x + 256u * 8u; i0 < uwtot; i0 += 256u * 8u) {     // larger layers: further batches of 8
             F f[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] = wload(i0 + 256 * k);
+            for (int k = 0; k < 8; ++k) f[k] = wload(i0 + 256u * k);
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const long i = i0 + 256 * k;
-                if (i < wtot) frag<T>::store(wlds + i * 8, wkeep(i) ? f[k] : frag<T>::zero());
+                const unsigned i = i0 + 256u * k;
+                if (i < uwtot) frag<T>::store(wlds + i * 8u, wkeep(i) ? f[k] : frag<T>::zero());
             }
         }
     }
@@ -612,10 +611,10 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         if (has_next) {
             if (nchunk == nchunks) {
                 nchunk = 0;
-                ntx += sx; int c = ntx >= tiles_x; ntx -= c ? tiles_x : 0;
-                nty += sy + c; c = nty >= tiles_y; nty -= c ? tiles_y : 0;
-                ntz += sz + c; c = ntz >= tiles_z; ntz -= c ? tiles_z : 0;
-                nn += sn + c;
+                ntx += 1; int c = ntx >= tiles_x; ntx -= c ? tiles_x : 0;
+                nty += c; c = nty >= tiles_y; nty -= c ? tiles_y : 0;
+                ntz += c; c = ntz >= tiles_z; ntz -= c ? tiles_z : 0;
+                nn += c;
             }
             halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW, ONE>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, ntz * G::TD, nty * G::TH, ntx * G::TW, nchunk, lanesel);
             wstage_issue(nchunk);
@@ -746,9 +745,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float s = ssum[t][j], q = ssq[t][j];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+                const float s = row16_sum(ssum[t][j]), q = row16_sum(ssq[t][j]);
                 if (px == 0) {
                     atomicAdd(&bstat[t * 16 + 4 * g + j], s);
                     atomicAdd(&bstat[16 * NT + t * 16 + 4 * g + j], q);

@@ -29,7 +29,7 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
     if (prologue) { P.src[0].scale = sc; P.src[0].shift = sh; P.src[0].act = 1; }
     P.nsrc = 1; P.N = N; P.D = D; P.H = H; P.W = W; P.ID = D; P.IH = H; P.IW = W; P.ksize = KS; P.stride = 1; P.dims = D3 ? 3 : 2;
     P.wpacked = wp; P.out = y; P.Cout = Cout; P.out_ld = Cout; P.stats = stats ? st : nullptr; P.stats_reps = 8; P.dtype = CHAP_BF16;
-    auto kern = conv_fwd_kernel<T, KS, 1, D3, KC, NT, MR, false, WLDS, ZW>;
+    auto kern = conv_fwd_kernel<T, KS, 1, D3, KC, NT, MR, false, WLDS, ZW, true>;
     size_t lds_fixed_only = conv_lds_fixed_bytes<T, KS, 1, D3, KC, MR, ZW>(NT) + 2 * CONV_MAX_AFFINE_C * 4;
     const bool fits = conv_wstaged<T, KS, 1, D3, KC, NT, MR, ZW>();
     const int wstage = WLDS || fits;
