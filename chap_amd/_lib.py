@@ -122,6 +122,19 @@ class KlParams(C.Structure):
                 ("gscale", _f32), ("gscale_dev", _vp), ("N", _i32), ("C", _i32), ("P", _i32)]
 
 
+class EnsembleParams(C.Structure):
+    _fields_ = [("logits1", _vp), ("logits2", _vp), ("prob", _vp), ("label", _vp), ("N", _i32), ("C", _i32), ("P", C.c_int64), ("mode", _i32)]
+
+
+class WindowAccParams(C.Structure):
+    _fields_ = [("logits", _vp), ("origins", _vp), ("score", _vp), ("cnt", _vp), ("npatch", _i32), ("C", _i32),
+                ("pw", _i32), ("ph", _i32), ("pd", _i32), ("W", _i32), ("H", _i32), ("D", _i32)]
+
+
+class WindowFinParams(C.Structure):
+    _fields_ = [("score", _vp), ("cnt", _vp), ("label", _vp), ("C", _i32), ("P", C.c_int64)]
+
+
 class L2NormParams(C.Structure):
     _fields_ = [("in_", _vp), ("out", _vp), ("N", _i32), ("P", _i32), ("eps", _f32), ("ws", _vp)]
 
@@ -170,6 +183,7 @@ _SIGS = {  # name -> (restype, params struct or None)
     "chap_bn_eval_affine": BnEvalParams, "chap_act_bwd_reduce": ActBwdParams, "chap_act_bwd_apply": ActBwdParams,
     "chap_act_pool2": PoolParams, "chap_upsample2x": UpsampleParams, "chap_upsample2x_bwd": UpsampleBwdParams,
     "chap_planar_to_cl": PlanarToClParams, "chap_channel_sum": ChanSumParams, "chap_cl_to_planar": ClToPlanarParams,
+    "chap_ensemble_argmax": EnsembleParams, "chap_window_accumulate": WindowAccParams, "chap_window_finalize": WindowFinParams,
     "chap_mix_loss_fwd": MixLossParams, "chap_mix_loss_bwd": MixLossParams, "chap_pseudo_block": PseudoParams,
     "chap_kl_fwd_bwd": KlParams, "chap_l2_normalize": L2NormParams, "chap_perturb": AxpyParams,
     "chap_rand_uniform": RandParams, "chap_keep_mask": KeepMaskParams, "chap_chan_mask": ChanMaskParams,

@@ -222,3 +222,87 @@ extern "C" int chap_kl_fwd_bwd(const chap_kl_params* p, void* stream) {
     CHAP_LAUNCH_CHECK("chap_kl_fwd_bwd");
     return CHAP_OK;
 }
+
+
+// =========================================================================================
+// Inference callers (val_2D.py:54-97, test_3D_util.py:14-79): ensemble + softmax + argmax, sliding-window scores.
+constexpr int INFER_MAXC = 8;
+
+__device__ __forceinline__ void softmax_c(float* v, int C) {
+    float m = v[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, v[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) { v[c] = __expf(v[c] - m); s += v[c]; }
+    const float inv = 1.f / s;
+    for (int c = 0; c < C; ++c) v[c] *= inv;
+}
+
+__global__ __launch_bounds__(256) void ensemble_argmax_kernel(const chap_ensemble_params P) {
+    const long total = (long)P.N * P.P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = i / P.P, pp = i % P.P;
+        const long base = n * P.C * P.P + pp;
+        float a[INFER_MAXC], b[INFER_MAXC];
+        for (int c = 0; c < P.C; ++c) {
+            a[c] = (P.mode != 1) ? P.logits1[base + c * P.P] : P.logits2[base + c * P.P];
+            b[c] = (P.mode >= 2) ? P.logits2[base + c * P.P] : 0.f;
+        }
+        if (P.mode == 2) { for (int c = 0; c < P.C; ++c) a[c] = (a[c] + b[c]) / 2.0f; }
+        softmax_c(a, P.C);
+        if (P.mode == 3) { softmax_c(b, P.C); for (int c = 0; c < P.C; ++c) a[c] = (a[c] + b[c]) / 2.0f; }
+        int best = 0;
+        for (int c = 1; c < P.C; ++c) if (a[c] > a[best]) best = c;
+        P.label[i] = (uint8_t)best;
+        if (P.prob) for (int c = 0; c < P.C; ++c) P.prob[base + c * P.P] = a[c];
+    }
+}
+extern "C" int chap_ensemble_argmax(const chap_ensemble_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->label && p->N > 0 && p->P > 0 && p->C >= 1 && p->C <= INFER_MAXC && p->mode >= 0 && p->mode <= 3, "chap_ensemble_argmax: bad argument");
+    CHAP_CHECK_ARG((p->mode == 1 || p->logits1) && (p->mode == 0 || p->logits2), "chap_ensemble_argmax: mode %d needs the other head", p->mode);
+    hipLaunchKernelGGL(ensemble_argmax_kernel, dim3(loss_blocks((long)p->N * p->P)), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_ensemble_argmax");
+    return CHAP_OK;
+}
+
+__global__ __launch_bounds__(256) void window_accumulate_kernel(const chap_window_acc_params P) {
+    const long pvox = (long)P.pw * P.ph * P.pd, total = (long)P.npatch * pvox;
+    const long vol = (long)P.W * P.H * P.D;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i / pvox); long r = i % pvox;
+        const int z = (int)(r % P.pd); r /= P.pd;
+        const int y = (int)(r % P.ph); const int x = (int)(r / P.ph);
+        const float* lg = P.logits + (long)k * P.C * pvox + (i % pvox);
+        float v[INFER_MAXC];
+        for (int c = 0; c < P.C; ++c) v[c] = lg[c * pvox];
+        softmax_c(v, P.C);
+        const long o = ((long)(P.origins[3 * k] + x) * P.H + (P.origins[3 * k + 1] + y)) * P.D + (P.origins[3 * k + 2] + z);
+        for (int c = 0; c < P.C; ++c) atomicAdd(P.score + c * vol + o, v[c]);
+        atomicAdd(P.cnt + o, 1.f);
+    }
+}
+extern "C" int chap_window_accumulate(const chap_window_acc_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->logits && p->origins && p->score && p->cnt && p->npatch > 0 && p->C >= 1 && p->C <= INFER_MAXC, "chap_window_accumulate: bad argument");
+    CHAP_CHECK_ARG(p->pw > 0 && p->ph > 0 && p->pd > 0 && p->pw <= p->W && p->ph <= p->H && p->pd <= p->D, "chap_window_accumulate: patch larger than the volume");
+    hipLaunchKernelGGL(window_accumulate_kernel, dim3(loss_blocks((long)p->npatch * p->pw * p->ph * p->pd)), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_window_accumulate");
+    return CHAP_OK;
+}
+
+__global__ __launch_bounds__(256) void window_finalize_kernel(const chap_window_fin_params P) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < P.P; i += (long)gridDim.x * 256) {
+        const float cn = P.cnt[i];
+        int best = 0; float bv = 0.f;
+        for (int c = 0; c < P.C; ++c) {
+            const float v = P.score[c * P.P + i] / cn;           // 0/0 = NaN where no patch landed, as in the reference
+            P.score[c * P.P + i] = v;
+            if (c == 0 || v > bv) { best = c; bv = v; }
+        }
+        P.label[i] = (uint8_t)best;
+    }
+}
+extern "C" int chap_window_finalize(const chap_window_fin_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->score && p->cnt && p->label && p->C >= 1 && p->C <= INFER_MAXC && p->P > 0, "chap_window_finalize: bad argument");
+    hipLaunchKernelGGL(window_finalize_kernel, dim3(loss_blocks(p->P)), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_window_finalize");
+    return CHAP_OK;
+}

@@ -363,3 +363,40 @@ def sgd_step(param, grad, mom, lr_dev, momentum, weight_decay, grad_scale=1.0, z
     p.param, p.grad, p.grad2, p.mom, p.lr = param.data_ptr(), grad.data_ptr(), _p(grad2), mom.data_ptr(), lr_dev.data_ptr()
     p.momentum, p.weight_decay, p.grad_scale, p.n, p.zero_grad = momentum, weight_decay, grad_scale, param.numel(), int(zero_grad)
     L.call("chap_sgd_step", p, _stream())
+
+
+# ------------------------------------------------------------------------------------------
+# inference callers (val_2D.py:54-97, test_3D_util.py:14-79)
+ENSEMBLE_MODES = {"model1": 0, "model2": 1, "logit_ensemble": 2, "prob_ensemble": 3}
+
+
+def ensemble_argmax(logits1, logits2, mode, want_prob=False):
+    """logits*: fp32 [N, C, *spatial] (planar).  Returns (label uint8 [N, *spatial], prob or None)."""
+    ref = logits1 if logits1 is not None else logits2
+    N, Cc = ref.shape[0], ref.shape[1]
+    p = L.EnsembleParams()
+    label = torch.empty((N,) + tuple(ref.shape[2:]), dtype=torch.uint8, device=ref.device)
+    prob = torch.empty_like(ref) if want_prob else None
+    p.logits1, p.logits2, p.prob, p.label = _p(logits1), _p(logits2), _p(prob), label.data_ptr()
+    p.N, p.C, p.P, p.mode = N, Cc, ref[0, 0].numel(), ENSEMBLE_MODES[mode] if isinstance(mode, str) else mode
+    L.call("chap_ensemble_argmax", p, _stream())
+    return label, prob
+
+
+def window_accumulate(logits, origins, score, cnt):
+    """logits fp32 [K, C, pw, ph, pd]; origins int32 [K, 3]; score fp32 [C, W, H, D]; cnt fp32 [W, H, D] (both += )."""
+    p = L.WindowAccParams()
+    p.logits, p.origins, p.score, p.cnt = logits.data_ptr(), origins.data_ptr(), score.data_ptr(), cnt.data_ptr()
+    p.npatch, p.C = logits.shape[0], logits.shape[1]
+    p.pw, p.ph, p.pd = logits.shape[2:]
+    p.W, p.H, p.D = cnt.shape
+    L.call("chap_window_accumulate", p, _stream())
+
+
+def window_finalize(score, cnt):
+    """score /= cnt in place; returns label uint8 [W, H, D] = argmax over classes."""
+    p = L.WindowFinParams()
+    label = torch.empty(cnt.shape, dtype=torch.uint8, device=cnt.device)
+    p.score, p.cnt, p.label, p.C, p.P = score.data_ptr(), cnt.data_ptr(), label.data_ptr(), score.shape[0], cnt.numel()
+    L.call("chap_window_finalize", p, _stream())
+    return label

@@ -319,6 +319,27 @@ typedef struct { float* param; float* grad; float* grad2 /* optional second buck
                  float momentum, weight_decay, grad_scale; int64_t n; int32_t zero_grad; } chap_sgd_params;
 int chap_sgd_step(const chap_sgd_params* p, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Inference callers: the device-side parts of test_single_volume (val_2D.py:54-97) and of the
+ * sliding-window test_single_case (test_3D_util.py:14-79).
+ *
+ * chap_ensemble_argmax: prob = softmax of one head (mode 0: logits1, 1: logits2), of the mean logits
+ * (2: "logit_ensemble", val_2D.py:72-75) or the mean of the two softmaxes (3: "prob_ensemble", :76-80);
+ * label = argmax_c prob (first maximum, as torch.argmax).  logits fp32 planar [N][C][P].                 */
+typedef struct { const float* logits1; const float* logits2; float* prob /* [N][C][P] or NULL */; uint8_t* label /* [N][P] */;
+                 int32_t N, C; int64_t P; int32_t mode; } chap_ensemble_params;
+int chap_ensemble_argmax(const chap_ensemble_params* p, void* stream);
+
+/* chap_window_accumulate: score[:, xs:xs+pw, ys:ys+ph, zs:zs+pd] += softmax(logits), cnt[same] += 1
+ * (test_3D_util.py:62-69) for `npatch` patches at once: logits fp32 [npatch][C][pw][ph][pd], origins int32
+ * [npatch][3]; score fp32 [C][W][H][D], cnt fp32 [W][H][D].  Overlapping patches of ONE call are summed with
+ * float atomics in unspecified order (the reference's order is the loop order: last-bit differences).
+ * chap_window_finalize: label = argmax_c score/cnt (:70-71), uint8 [W][H][D]; score is normalised in place. */
+typedef struct { const float* logits; const int32_t* origins; float* score; float* cnt; int32_t npatch, C; int32_t pw, ph, pd; int32_t W, H, D; } chap_window_acc_params;
+int chap_window_accumulate(const chap_window_acc_params* p, void* stream);
+typedef struct { float* score; const float* cnt; uint8_t* label; int32_t C; int64_t P; } chap_window_fin_params;
+int chap_window_finalize(const chap_window_fin_params* p, void* stream);
+
 /* Bandwidth calibration helper (tools/membw.py): grid-stride float4 copy with `blocks` blocks of 256. */
 int chap_debug_copy(const void* src, void* dst, int64_t bytes, int32_t blocks, void* stream);
 

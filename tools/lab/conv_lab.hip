@@ -38,8 +38,7 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
     int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, lds);
     long ntiles = (long)N * ((D + G::TD - 1) / G::TD) * ((H + G::TH - 1) / G::TH) * ((W + 15) / 16);
     int gy = (ntile16 + NT - 1) / NT;
-    for (int bpc = 1; bpc <= (D3 ? 2 : 8); bpc *= 2) {
-        if (bpc > 1 && bpc > occ) break;
+    for (int bpc = 1; bpc <= occ; bpc = (bpc * 2 <= occ || bpc == occ) ? bpc * 2 : occ) {
         long gx = std::min<long>((ntiles + 7) / 8 * 8, (long)256 * bpc / gy / 8 * 8);
         if (gx < 8) gx = 8;
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
