@@ -33,6 +33,14 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Sum over the lanes l, l+S, l+2S, ... of a DPP row (S = 2, 4 or 8; S >= 16: no-op) by cyclic row rotations.
+template <int S> __device__ __forceinline__ float row16_stride_sum(float v) {
+    if (S <= 2) CHAP_DPP_ADD(v, 0x122);     // row_ror:2
+    if (S <= 4) CHAP_DPP_ADD(v, 0x124);     // row_ror:4
+    if (S <= 8) CHAP_DPP_ADD(v, 0x128);     // row_ror:8
+    return v;
+}
+
 template <typename T> struct elem;
 template <> struct elem<float> {
     static __device__ __forceinline__ float get(float v) { return v; }

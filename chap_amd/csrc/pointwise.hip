@@ -644,7 +644,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float a = s0[j], b = s1[j];
-            for (int o = C8; o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+            // inside a 16-lane row: DPP rotations (C8 is wave-uniform); across rows: two shuffles
+            if (C8 == 2) { a = row16_stride_sum<2>(a); b = row16_stride_sum<2>(b); }
+            else if (C8 == 4) { a = row16_stride_sum<4>(a); b = row16_stride_sum<4>(b); }
+            else if (C8 == 8) { a = row16_stride_sum<8>(a); b = row16_stride_sum<8>(b); }
+            for (int o = (C8 > 16 ? C8 : 16); o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
             if ((threadIdx.x & 63) < C8) { atomicAdd(&red[c8 + j], a); atomicAdd(&red[C + c8 + j], b); }
         }
         __syncthreads();
