@@ -15,6 +15,7 @@
 // registers across tiles and flushed with ONE float atomic per channel per block.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 #ifndef CHAP_CONV_MINWAVES
 #define CHAP_CONV_MINWAVES 1      // __launch_bounds__ 2nd argument (waves per SIMD) -- lab knob
@@ -697,29 +698,35 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
                     }
                 }
             } else {
-                // channel-last, 4 channels per lane: vector stores at (uniform base) + (32-bit lane offset)
+                // channel-last, 4 channels per lane: vector stores at (uniform base) + (32-bit lane offset).  Interior
+                // tiles with a full channel group (wave-uniform test; nearly all of them) skip the per-lane validity:
+                // no selects in the statistics, no exec masking around the stores.
                 char* ob = (char*)P.out + o0 * (P.out_f32 ? 4 : (long)sizeof(T));
+                const bool full = (x0 + G::TW <= P.W) && (y0 + G::TH <= P.H) && (!ZW || z0 + G::TD <= P.D) && ((nt0 + NT) * 16 <= P.Cout);
+                auto emit = [&](auto FULL) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const bool cok = (nt0 + t) * 16 + 4 * g < P.Cout;
+                    for (int t = 0; t < NT; ++t) {
+                        const bool cok = (nt0 + t) * 16 + 4 * g < P.Cout;
 #pragma unroll
-                    for (int m = 0; m < MR; ++m) {
-                        const int row = ZW ? m : wave * MR + m;
-                        const bool valid = xok && zok && cok && (y0 + row < P.H);
-                        float v[4];
+                        for (int m = 0; m < MR; ++m) {
+                            const int row = ZW ? m : wave * MR + m;
+                            const bool valid = decltype(FULL)::value || (xok && zok && cok && (y0 + row < P.H));
+                            float v[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = acc[m][t][j] + bj[t][j];
-                        if (do_stats) {
+                            for (int j = 0; j < 4; ++j) v[j] = acc[m][t][j] + bj[t][j];
+                            if (do_stats) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) { const float vs = valid ? v[j] : 0.f; ssum[t][j] += vs; ssq[t][j] += vs * vs; }
-                        }
-                        if (CHAP_ABLATE & 8) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
-                        const unsigned oi = (unsigned)(row * orow + zw_off + ooff[t]);
-                        if (valid) {
-                            if (P.out_f32) st4((float*)(ob + oi * 4u), v); else st4((T*)(ob + oi * (unsigned)sizeof(T)), v);
+                                for (int j = 0; j < 4; ++j) { const float vs = valid ? v[j] : 0.f; ssum[t][j] += vs; ssq[t][j] += vs * vs; }
+                            }
+                            if (CHAP_ABLATE & 8) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
+                            const unsigned oi = (unsigned)(row * orow + zw_off + ooff[t]);
+                            if (valid) {
+                                if (P.out_f32) st4((float*)(ob + oi * 4u), v); else st4((T*)(ob + oi * (unsigned)sizeof(T)), v);
+                            }
                         }
                     }
-                }
+                };
+                if (full) emit(std::true_type{}); else emit(std::false_type{});
             }
         }
         CHAP_STAMP(3);
