@@ -161,6 +161,30 @@ class ChapStep:
         self.opt.set_lr(lr_)
         return lr_
 
+    # ------------------------------------------------------------------ checkpoint / resume (build extension)
+    def state_dict(self):
+        """Everything a long run needs to continue exactly where it stopped.  'model' is the reference's checkpoint
+        (what train_ours_2D.py:428-435 saves with torch.save(model.state_dict())); the rest is absent upstream:
+        momentum buffer, iteration counter (drives poly LR and the consistency ramp), numpy RNG state (BCP box
+        offsets) and the dropout / VAT noise RNG epoch."""
+        rng = self.model._rng
+        return {"model": {k: v.detach().clone() for k, v in self.model.state_dict().items()},
+                "momentum": self.opt.mom.detach().clone(), "iter_num": int(self.iter_num),
+                "lr": float(self.opt.param_groups[0]["lr"]), "numpy_rng": np.random.get_state(),
+                "rng": {"base": rng.base, "count": rng.count, "seed_dev": int(rng.seed_dev.item())}}
+
+    def load_state_dict(self, st):
+        self.model.load_state_dict(st["model"], strict=True)
+        self.opt.mom.copy_(st["momentum"])
+        self.iter_num = int(st["iter_num"])
+        self.opt.set_lr(st["lr"])
+        np.random.set_state(st["numpy_rng"])
+        rng = self.model._rng
+        rng.base, rng.count = int(st["rng"]["base"]), int(st["rng"]["count"])
+        rng.seed_dev.fill_(int(st["rng"]["seed_dev"]))
+        self.grad_both.zero_()
+        return self
+
     # ------------------------------------------------------------------ the device work
     def exchange_and_update(self):
         """(data-parallel) all-reduce of both gradient buckets, then optimizer.step() (:381-383): the fused SGD

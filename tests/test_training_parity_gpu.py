@@ -121,3 +121,55 @@ def test_trained_model_dice_matches_oracle_inference():
     assert d_ref.mean() > 0.3, d_ref                        # the trained model really segments something
     assert np.abs(d_ref - d_hip).max() <= 1e-3, (d_ref, d_hip)
     assert (p_ref == p_hip).mean() > 0.999
+
+
+def test_resume_continues_the_run():
+    """Checkpoint / resume (build extension): 2 iterations, state_dict(), a FRESH model + ChapStep loaded from it,
+    2 more iterations == 4 uninterrupted iterations (same injected randomness; BCP boxes come from numpy's RNG,
+    which the checkpoint carries).  Equality up to the float-atomic summation order of the BN statistics."""
+    B, lbs, H, W = 8, 4, 64, 64
+    U = B - lbs
+    args = dict(labeled_bs=lbs, batch_size=B, vat_iters=1, base_lr=0.01)
+    state = oinit.dual_decoder_2d_state(321)
+
+    def inj(it):
+        d = {"drop_A": oinit.drop_masks_2d(10 * it + 1, U, H, W), "drop_B": oinit.drop_masks_2d(10 * it + 2, lbs // 2 + U // 2, H, W),
+             "drop_V0": oinit.drop_masks_2d(10 * it + 3, U, H, W), "drop_VF": oinit.drop_masks_2d(10 * it + 4, U, H, W),
+             "d0": torch.rand(U, 1, H, W, generator=torch.Generator().manual_seed(10 * it + 5)) - 0.5}
+        return {k: (cl_masks(v) if k.startswith("drop") else v.to(DEV)) for k, v in d.items()}
+
+    def fresh():
+        m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train()
+        m.load_state_dict(state, strict=True)
+        return m, ChapStep(m, args)
+
+    def run(step, its):
+        for it in its:
+            vol, lab = ots.synthetic_batch(2000 + it, lbs, U, H, W)
+            step.step(vol.to(DEV), lab.to(DEV), inject=inj(it))       # box offsets: np.random (train_ours_2D.py:97-98)
+
+    def dist(ma, mb):
+        sa, sb = ma.state_dict(), mb.state_dict()
+        return max(((sa[k].float() - sb[k].float()).abs().max() / sa[k].float().abs().max().clamp_min(1.0)).item() for k in sa)
+
+    np.random.seed(99)
+    m_a, s_a = fresh()
+    run(s_a, range(4))
+    np.random.seed(99)
+    m_a2, s_a2 = fresh()                                               # the same run again: the noise floor of the comparison
+    run(s_a2, range(4))                                                # (float atomics in the BN sums x arg-max pseudo labels)
+    np.random.seed(99)
+    m_b, s_b = fresh()
+    run(s_b, range(2))
+    ckpt = s_b.state_dict()
+    assert set(ckpt["model"]) == set(state) and ckpt["iter_num"] == 2
+    np.random.seed(12345)                                              # the checkpoint must restore the box RNG
+    m_c = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train()
+    s_c = ChapStep(m_c, args).load_state_dict(ckpt)
+    assert s_c.iter_num == 2 and abs(s_c.opt.param_groups[0]["lr"] - ots.poly_lr(0.01, 2, 30000)) < 1e-12
+    assert torch.equal(s_c.opt.mom, s_b.opt.mom) and all(torch.equal(v, m_c.state_dict()[k]) for k, v in m_b.state_dict().items())
+    run(s_c, range(2, 4))
+    noise, resumed = dist(m_a, m_a2), dist(m_a, m_c)
+    assert resumed <= 4 * max(noise, 1e-5), (resumed, noise)
+    wrong = dist(m_a, m_b)                                             # a run that stopped after 2 iterations is far away
+    assert wrong > 10 * resumed, (wrong, resumed)
