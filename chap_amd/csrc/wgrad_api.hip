@@ -18,7 +18,7 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     const bool small_tile = (p->dims == 3 && p->ksize >= 2);   // 3D geometries use 4 x 16 tiles (MR = 1)
     const int TH = small_tile ? 4 : 8;
     q->ntiles = (long)p->N * p->D * cdiv(p->H, TH) * cdiv(p->W, 16);
-    const long pairs = (long)(q->Ca / q->KC) * cdiv(q->Cb, 32);
+    const long pairs = (long)(q->Ca / q->KC) * cdiv(q->Cb, q->Cb <= 16 ? 16 : 32);
     long ns = 512 / pairs;       // persistent, pipelined blocks: ~2 per CU are enough; fewer splits = fewer slab bytes to reduce
     if (ns < 1) ns = 1;
     if (ns > q->ntiles) ns = q->ntiles;

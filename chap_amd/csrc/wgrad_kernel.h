@@ -12,14 +12,15 @@
 #pragma once
 #include "conv_kernel.h"
 
-constexpr int WG_BN = 32;                       // B channels per block
+constexpr int WG_BN = 32;                       // B channels per block (16 for layers with <= 16 output channels)
+constexpr int WG_BDUMMY = 8;                    // elements behind each B tile: store target of threads without a B unit
 template <typename T> __host__ __device__ constexpr int wg_psb() { return sizeof(T) == 2 ? 40 : 36; }
 
-template <typename T, int KS, int ST, bool D3, int KC, int MR>
+template <typename T, int KS, int ST, bool D3, int KC, int MR, int BN = WG_BN>
 __host__ __device__ constexpr size_t wgrad_lds_bytes() {
     typedef conv_geom<KS, ST, D3, MR> G;
-    return 2 * ((size_t)G::HP * pix_stride<T, KC>() + HALO_DUMMY + (size_t)G::TH * G::TW * wg_psb<T>()) * sizeof(T)    // double-buffered A halo + B tile
-           + 3 * CONV_MAX_AFFINE_C * sizeof(float) + 4 * WG_BN * sizeof(float);                            // affine caches (A0, A1, B), db partials
+    return 2 * ((size_t)G::HP * pix_stride<T, KC>() + HALO_DUMMY + (size_t)G::TH * G::TW * wg_psb<T>() + WG_BDUMMY) * sizeof(T)    // double-buffered A halo + B tile
+           + 3 * CONV_MAX_AFFINE_C * sizeof(float) + 4 * BN * sizeof(float);                               // affine caches (A0, A1, B), db partials
 }
 
 __device__ __forceinline__ s16x4 lds_tr16(const bf16_t* p) {
@@ -28,24 +29,23 @@ __device__ __forceinline__ s16x4 lds_tr16(const bf16_t* p) {
 
 // Persistent blocks, one (A-chunk, B-chunk, split) each: the A halo and the B tile of tile i+1 are
 // fetched into registers while tile i runs on the MFMA pipe out of LDS (same scheme as conv_fwd_kernel).
-template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2>
+template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int BN = WG_BN>
 __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, float* __restrict__ ws, float* __restrict__ ws_db,
                                                     int nsplit, int Ca, int Cb) {
     typedef conv_geom<KS, ST, D3, MR> G;
     typedef typename frag<T>::type F;
     constexpr int GPT = KC / 8, PS = pix_stride<T, KC>(), PSB = wg_psb<T>();
-    constexpr int KCT = KC / 16, NTB = WG_BN / 16;
+    constexpr int KCT = KC / 16, NTB = BN / 16, CG = BN / 8;     // B: 16-channel MFMA tiles, 8-channel staging groups
     constexpr int PAIRS = G::NTAPS * KCT, MAXP = (PAIRS + 3) / 4;
     constexpr int NKCH = G::TH * G::TW / 32;            // 32-pixel k-chunks per tile
     constexpr int UNITS = (G::HP * GPT + 255) / 256;
-    constexpr int BUNITS = (G::TH * G::TW * (WG_BN / 8) + 255) / 256;
-    static_assert((G::TH * G::TW * (WG_BN / 8)) % 256 == 0, "B tile units must fill the block exactly");
+    constexpr int BUNITS = (G::TH * G::TW * CG + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* halo0 = (T*)smem;
     T* halo1 = halo0 + (size_t)G::HP * PS + HALO_DUMMY;
     T* bt0 = halo1 + (size_t)G::HP * PS + HALO_DUMMY;
-    T* bt1 = bt0 + (size_t)G::TH * G::TW * PSB;
-    float* aff = (float*)(bt1 + (size_t)G::TH * G::TW * PSB);       // [A0 | A1 | B] x [scale | shift]
+    T* bt1 = bt0 + (size_t)G::TH * G::TW * PSB + WG_BDUMMY;
+    float* aff = (float*)(bt1 + (size_t)G::TH * G::TW * PSB + WG_BDUMMY);       // [A0 | A1 | B] x [scale | shift]
     float* dbred = aff + 3 * CONV_MAX_AFFINE_C;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -67,14 +67,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
     make_units<G, GPT, PS, UNITS>(U, P.IH, P.IW);
     const bool lanesel = !ADD2 && P.na > 1 && (P.a[0].C % KC) != 0;
     int b_yx[BUNITS], b_rel[BUNITS], b_lds[BUNITS];     // B tile units: (row << 8 | col), pixel offset, LDS offset; channel = nb*32 + (tid % 4) * 8
-    const int bc8 = (threadIdx.x & (WG_BN / 8 - 1)) * 8;
-    const int cbB = nb * WG_BN + bc8;
+    const int bc8 = (threadIdx.x & (CG - 1)) * 8;
+    const int cbB = nb * BN + bc8;
     const bool bchan_ok = cbB < Cb;
 #pragma unroll
     for (int j = 0; j < BUNITS; ++j) {
         const int u = threadIdx.x + 256 * j;
-        const int pix = u / (WG_BN / 8);
-        b_yx[j] = -1; b_rel[j] = 0; b_lds[j] = 0;
+        const int pix = u / CG;
+        b_yx[j] = -1; b_rel[j] = 0; b_lds[j] = G::TH * G::TW * PSB;      // no such unit: loads the tile origin, stores to the dummy slot
         if (pix < G::TH * G::TW) {
             const int row = pix / G::TW, col = pix % G::TW;
             b_yx[j] = (row << 8) | col;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
             for (int k = 0; k < 4; ++k) { const f32x2 m = {bcm[2 * k], bcm[2 * k + 1]}; a[k] *= m; b[k] *= m; }
         }
 #pragma unroll
-        for (int j = 0; j < BUNITS; ++j) {                      // (TH*16*4) % 256 == 0: every thread has all BUNITS units
+        for (int j = 0; j < BUNITS; ++j) {                      // threads without a unit stage zeros into the dummy slot
             T* dst = bt + b_lds[j];
             const bool ok = (bok >> j) & 1u;
             if (plainB) {
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
             const int tap = pair / KCT, kct = pair % KCT;
 #pragma unroll
             for (int t = 0; t < NTB; ++t) {
-                const int kn = nb * WG_BN + t * 16 + l15;
+                const int kn = nb * BN + t * 16 + l15;
                 if (kn < Cb) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -274,15 +274,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
         }
     }
     if (want_db) {
-        // threads with equal (tid % 4) hold the same 8 channels: shuffle over lanes 4,8,16,32 apart, then across waves via LDS
+        // threads with equal (tid % CG) hold the same 8 channels: shuffle over lanes CG, 2CG, .. apart, then across waves via LDS
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float v = dbsum[j];
-            for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-            if (lane < 4) dbred[wave * WG_BN + lane * 8 + j] = v;
+            for (int o = CG; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+            if (lane < CG) dbred[wave * BN + lane * 8 + j] = v;
         }
         __syncthreads();
-        if (threadIdx.x < WG_BN && nb * WG_BN + threadIdx.x < Cb)
-            ws_db[(long)split * Cb + nb * WG_BN + threadIdx.x] = dbred[threadIdx.x] + dbred[WG_BN + threadIdx.x] + dbred[2 * WG_BN + threadIdx.x] + dbred[3 * WG_BN + threadIdx.x];
+        if (threadIdx.x < BN && nb * BN + threadIdx.x < Cb)
+            ws_db[(long)split * Cb + nb * BN + threadIdx.x] = dbred[threadIdx.x] + dbred[BN + threadIdx.x] + dbred[2 * BN + threadIdx.x] + dbred[3 * BN + threadIdx.x];
     }
 }
