@@ -516,16 +516,18 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
 
     f32x4 acc[MR][NT];
     float ssum[NT][4], ssq[NT][4], bj[NT][4];
+    // bias: all loads first (index clamped, no branch, no use in between), the selects afterwards -- a use right
+    // behind each load makes the compiler wait for it (and for every prefetch issued above) NT*4 times in a row
+    {
+        const float* bsrc = P.bias ? P.bias : (const float*)P.wpacked;          // wave-uniform; any valid address when there is no bias
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int nl = (nt0 + t) * 16 + 4 * g;
-        const int cb = P.out_mode == 1 ? (nl % P.out_Cn) : nl;
+        for (int t = 0; t < NT; ++t) {
+            const int nl = (nt0 + t) * 16 + 4 * g;
+            const int cb = P.out_mode == 1 ? (nl % P.out_Cn) : nl;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            ssum[t][j] = 0.f; ssq[t][j] = 0.f; bj[t][j] = 0.f;
-            if (P.bias) {                                        // wave-uniform; index clamped instead of a lane branch
-                const float b = P.bias[nl + j < P.Cout ? cb + j : 0];
-                bj[t][j] = nl + j < P.Cout ? b : 0.f;
+            for (int j = 0; j < 4; ++j) {
+                ssum[t][j] = 0.f; ssq[t][j] = 0.f;
+                bj[t][j] = bsrc[(P.bias && nl + j < P.Cout) ? cb + j : 0];
             }
         }
     }
@@ -558,6 +560,12 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
                 if (i < uwtot) frag<T>::store(wlds + i * 8u, wkeep(i) ? f[k] : frag<T>::zero());
             }
         }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int nl = (nt0 + t) * 16 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bj[t][j] = (P.bias && nl + j < P.Cout) ? bj[t][j] : 0.f;
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
