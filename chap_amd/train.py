@@ -215,22 +215,29 @@ class ChapStep:
         with torch.no_grad():
             pre_ab1, pre_ab2 = model(uimg_ab, drop_masks=inject.get("drop_A"))
             outputs_soft1, outputs_soft2, pseudo_outputs1, pseudo_outputs2, knowledge = ops.pseudo_block(pre_ab1, pre_ab2)
-            if a["nms"]:
-                plab1 = ops.largest_cc(pseudo_outputs1, nc)
-                plab2 = ops.largest_cc(pseudo_outputs2, nc)
-            else:
-                plab1, plab2 = pseudo_outputs1, pseudo_outputs2
-            plab_a1, plab_b1 = plab1[:usub], plab1[usub:]
-            plab_a2, plab_b2 = plab2[:usub], plab2[usub:]
-            loss_mask = torch.empty(lsub, *volume_batch.shape[2:], dtype=torch.int64, device=volume_batch.device)
-            ops.box_mask(loss_mask, self.box)
-            # ---- BCP mixing (:335-338): net_input_mix = cat(net_input_l, net_input_unl)
-            net_input_mix = torch.empty((lsub + usub,) + tuple(volume_batch.shape[1:]), dtype=torch.float32, device=volume_batch.device)
-            ops.box_mix(img_b, uimg_b, net_input_mix[:lsub], self.box)       # img_b*mask + uimg_b*(1-mask)
-            ops.box_mix(uimg_a, img_a, net_input_mix[lsub:], self.box)       # uimg_a*mask + img_a*(1-mask)
+
+        # ---- largest-CC filter, loss mask and BCP mixing (:326-338) feed pass B only: they run at the head of the
+        #      pass-B branch, off the critical path (the VAT branch needs the soft / arg-max outputs, not these)
+        def mix_inputs():
+            with torch.no_grad():
+                if a["nms"]:
+                    plab1 = ops.largest_cc(pseudo_outputs1, nc)
+                    plab2 = ops.largest_cc(pseudo_outputs2, nc)
+                else:
+                    plab1, plab2 = pseudo_outputs1, pseudo_outputs2
+                loss_mask = torch.empty(lsub, *volume_batch.shape[2:], dtype=torch.int64, device=volume_batch.device)
+                ops.box_mask(loss_mask, self.box)
+                # BCP mixing (:335-338): net_input_mix = cat(net_input_l, net_input_unl)
+                net_input_mix = torch.empty((lsub + usub,) + tuple(volume_batch.shape[1:]), dtype=torch.float32, device=volume_batch.device)
+                ops.box_mix(img_b, uimg_b, net_input_mix[:lsub], self.box)       # img_b*mask + uimg_b*(1-mask)
+                ops.box_mix(uimg_a, img_a, net_input_mix[lsub:], self.box)       # uimg_a*mask + img_a*(1-mask)
+            return plab1, plab2, loss_mask, net_input_mix
 
         # ---- pass B + the four mix_loss terms (:339-351)
         def pass_b():
+            plab1, plab2, loss_mask, net_input_mix = mix_inputs()
+            plab_a1, plab_b1 = plab1[:usub], plab1[usub:]
+            plab_a2, plab_b2 = plab2[:usub], plab2[usub:]
             out_mix1, out_mix2 = model(net_input_mix, drop_masks=inject.get("drop_B"))
             d1, d2 = torch.empty_like(out_mix1), torch.empty_like(out_mix2)
             terms = (  # (logits, dlogits, img_l, patch_l, unlab)
