@@ -196,7 +196,7 @@ def main():
 
     from chap_amd.networks import DualDecoder, DualDecoder3d
     from chap_amd.train import ChapStep
-    from oracle import train_step as ots   # synthetic data generator only (data, not the checker)
+    from chap_amd import synthetic as ots   # fixed-seed synthetic inputs; the oracle is only used by cpu_baseline()
 
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     d3 = args.config == "3d"

@@ -3,7 +3,7 @@
 3D: test_single_case recipe, V-Net, 112x112x80 patches over a 160x160x96 volume, stride 18 / 4 as in test_LA.py:50-53
      (bounded: stride_xy 48, stride_z 16 so the CPU leg finishes)."""
 import os, sys, time, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from chap_amd import inference

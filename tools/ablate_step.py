@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from chap_amd.networks import DualDecoder, DualDecoder3d
 from chap_amd.train import ChapStep
-from oracle import train_step as ots
+from chap_amd import synthetic as ots
 
 def run(cfg, mode):
     dev = "cuda"
