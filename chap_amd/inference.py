@@ -5,7 +5,8 @@ softmax, argmax, zoom back) and `test_single_case` mirrors `code/test_3D_util.py
 window, softmax score accumulation, count normalisation, argmax).  Same names, arguments and return values; the
 differences are internal: slices / patches go through the network in batches, the ensemble + softmax + argmax and
 the score-map accumulation run in HIP kernels (`chap_ensemble_argmax`, `chap_window_accumulate/finalize`) and
-nothing is copied to the host per slice / per patch.  Nearest-neighbour zoom stays scipy's (as in the reference).
+nothing is copied to the host per slice / per patch.  The nearest-neighbour zoom is an index plan that reproduces
+scipy.ndimage.zoom(order=0) bit for bit (including its edge quirk) and runs on the device.
 """
 import math
 
@@ -13,6 +14,39 @@ import numpy as np
 import torch
 
 from . import ops
+
+
+_ZOOM_PLANS = {}
+
+
+def _zoom0_axis(n_in, factor):
+    """Index plan of scipy.ndimage.zoom(order=0, mode='constant', grid_mode=False) along one axis: output size
+    round(n_in * factor); output o reads input floor(o * (n_in-1)/(n_out-1) + 0.5); a coordinate that floating point
+    pushes past n_in - 1 is *outside* and yields the constant 0 (scipy's edge quirk, reproduced on purpose: the
+    reference's predictions contain it).  Checked against scipy for 6 800 size pairs (tests/test_oracle_inference_cpu.py)."""
+    key = (int(n_in), float(factor))
+    plan = _ZOOM_PLANS.get(key)
+    if plan is None:
+        n_out = int(round(n_in * factor))
+        if n_out <= 1:
+            idx, inside = np.zeros(max(n_out, 1), dtype=np.int64), np.ones(max(n_out, 1), dtype=bool)
+        else:
+            c = np.arange(n_out, dtype=np.float64) * (float(n_in - 1) / float(n_out - 1))
+            inside = (c >= 0) & (c <= n_in - 1)
+            idx = np.clip(np.floor(c + 0.5).astype(np.int64), 0, n_in - 1)
+        plan = (torch.from_numpy(idx), torch.from_numpy(inside))
+        _ZOOM_PLANS[key] = plan
+    return plan
+
+
+def zoom0(t, factors):
+    """Nearest-neighbour zoom of the last two dims of a torch tensor, bit-identical to scipy.ndimage.zoom(order=0)."""
+    iy, my = _zoom0_axis(t.shape[-2], factors[0])
+    ix, mx = _zoom0_axis(t.shape[-1], factors[1])
+    iy, my, ix, mx = iy.to(t.device), my.to(t.device), ix.to(t.device), mx.to(t.device)
+    out = t.index_select(-2, iy).index_select(-1, ix)
+    mask = my[:, None] & mx[None, :]
+    return torch.where(mask, out, torch.zeros((), dtype=t.dtype, device=t.device))
 
 
 def _dice_hd95(pred, gt):
@@ -32,14 +66,14 @@ def _dice_hd95(pred, gt):
 
 def predict_volume(image, net, patch_size=(256, 256), model_type="logit_ensemble", device="cuda:0", batch=32):
     """image: numpy [S, X, Y] -> prediction uint8 [S, X, Y] (the loop body of test_single_volume, all slices batched)."""
-    from scipy.ndimage import zoom
     S, x, y = image.shape
-    zoomed = np.stack([zoom(image[i], (patch_size[0] / x, patch_size[1] / y), order=0) for i in range(S)])
+    vol = torch.from_numpy(np.ascontiguousarray(image)).to(device)
+    zoomed = zoom0(vol, (patch_size[0] / x, patch_size[1] / y))          # the reference's per-slice zoom(order=0), on the device
     net.eval()
-    out = np.zeros((S, patch_size[0], patch_size[1]), dtype=np.uint8)
+    out = torch.empty((S,) + tuple(zoomed.shape[1:]), dtype=torch.uint8, device=device)
     with torch.no_grad():
         for s0 in range(0, S, batch):
-            inp = torch.from_numpy(zoomed[s0:s0 + batch]).unsqueeze(1).float().to(device)
+            inp = zoomed[s0:s0 + batch].unsqueeze(1).float().contiguous()
             o = net(inp)
             if isinstance(o, (tuple, list)):
                 o1, o2 = o[0], o[1]
@@ -47,9 +81,9 @@ def predict_volume(image, net, patch_size=(256, 256), model_type="logit_ensemble
                 o1, o2 = o, None
             mode = model_type if o2 is not None else "model1"
             label, _ = ops.ensemble_argmax(o1.contiguous(), None if o2 is None else o2.contiguous(), mode)
-            out[s0:s0 + batch] = label.cpu().numpy()
-    pred = np.stack([zoom(out[i], (x / patch_size[0], y / patch_size[1]), order=0) for i in range(S)])
-    return pred
+            out[s0:s0 + batch] = label
+    pred = zoom0(out, (x / patch_size[0], y / patch_size[1]))
+    return pred.cpu().numpy()
 
 
 def test_single_volume(image, label, net, classes, patch_size=[256, 256], model_type="unet", device="cuda:0", batch=32):

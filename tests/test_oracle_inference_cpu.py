@@ -28,3 +28,23 @@ def test_predict_volume_modes():
     assert (p2 == int(torch.argmax(w2.flatten()))).all()
     pl = oinf.predict_volume(img, net, (16, 16), "logit_ensemble")
     assert (pl == int(torch.argmax((w1 + w2).flatten()))).all()
+
+
+def test_zoom0_matches_scipy():
+    """chap_amd.inference.zoom0 == scipy.ndimage.zoom(order=0), including the outputs scipy zeroes at the far edge."""
+    from scipy.ndimage import zoom
+    from chap_amd.inference import zoom0
+    rng = np.random.default_rng(0)
+    n = 0
+    for (x, y) in [(50, 44), (216, 256), (256, 216), (224, 224), (63, 31), (512, 300), (30, 59), (7, 9), (100, 53)]:
+        for (px, py) in [(64, 64), (256, 256), (224, 224), (31, 100), (216, 8)]:
+            a = rng.random((x, y)).astype(np.float32) + 1.0
+            ref = zoom(a, (px / x, py / y), order=0)
+            got = zoom0(torch.from_numpy(a), (px / x, py / y)).numpy()
+            assert got.shape == ref.shape and np.array_equal(got, ref), (x, y, px, py)
+            lab = (rng.random((px, py)) * 4).astype(np.uint8)
+            refb = zoom(lab, (x / px, y / py), order=0)
+            gotb = zoom0(torch.from_numpy(lab), (x / px, y / py)).numpy()
+            assert np.array_equal(gotb, refb), (x, y, px, py)
+            n += 1
+    assert n == 45
