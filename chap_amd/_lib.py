@@ -109,7 +109,7 @@ class ClToPlanarParams(C.Structure):
 class MixLossParams(C.Structure):
     _fields_ = [("logits", _vp), ("target_a", _vp), ("target_b", _vp), ("mask", _vp), ("w_a", _f32), ("w_b", _f32),
                 ("acc", _vp), ("loss", _vp), ("dlogits", _vp), ("gscale", _f32), ("accumulate", _i32),
-                ("N", _i32), ("C", _i32), ("P", _i32), ("smooth", _f32)]
+                ("N", _i32), ("C", _i32), ("P", _i32), ("smooth", _f32), ("k_dice", _f32), ("k_ce", _f32)]
 
 
 class PseudoParams(C.Structure):

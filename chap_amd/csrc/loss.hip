@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void mix_loss_acc_kernel(const chap_mix_loss_p
         const long n = (unsigned)i / (unsigned)P, pp = (unsigned)i % (unsigned)P;
         float z[C], p[C], lse;
         softmax_px<C>(P_.logits, n * C * P + pp, P, z, p, lse);
-        const float m = (float)P_.mask[i];
-        const int t[2] = {(int)P_.target_a[i], (int)P_.target_b[i]};
+        const float m = P_.mask ? (float)P_.mask[i] : 1.f;
+        const int t[2] = {(int)P_.target_a[i], (int)(P_.target_b ? P_.target_b[i] : P_.target_a[i])};
         const float mk[2] = {m, 1.f - m};
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void mix_loss_acc_kernel(const chap_mix_loss_p
 }
 
 // mix_loss return triple (train_ours_2D.py:205-216) from the accumulators.
-__global__ void mix_loss_final_kernel(const float* acc, float* loss, int C, float w_a, float w_b, float smooth) {
+__global__ void mix_loss_final_kernel(const float* acc, float* loss, int C, float w_a, float w_b, float smooth, float k_dice, float k_ce) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int NA = 2 + 3 * C;
     float part[2];
@@ -77,7 +77,7 @@ __global__ void mix_loss_final_kernel(const float* acc, float* loss, int C, floa
         for (int c = 0; c < C; ++c) dice += 1.f - (2.f * a[1 + c] + smooth) / (a[1 + C + c] + a[1 + 2 * C + c] + smooth);
         dice = dice / C * w[k];
         const float ce = w[k] * a[0] / (a[1 + 3 * C] + 1e-16f);
-        part[k] = 0.5f * (dice + ce);
+        part[k] = k_dice * dice + k_ce * ce;
     }
     loss[0] = part[0]; loss[1] = part[1]; loss[2] = part[0] + part[1];
 }
@@ -94,9 +94,11 @@ __global__ __launch_bounds__(256) void mix_loss_bwd_kernel(const chap_mix_loss_p
         const long n = (unsigned)i / (unsigned)P, pp = (unsigned)i % (unsigned)P;
         float z[C], p[C], lse;
         softmax_px<C>(P_.logits, n * C * P + pp, P, z, p, lse);
-        const float m = (float)P_.mask[i];
-        const int t[2] = {(int)P_.target_a[i], (int)P_.target_b[i]};
+        const float m = P_.mask ? (float)P_.mask[i] : 1.f;
+        const int t[2] = {(int)P_.target_a[i], (int)(P_.target_b ? P_.target_b[i] : P_.target_a[i])};
         const float mk[2] = {m, 1.f - m};
+        const bool dflt = P_.k_dice == 0.f && P_.k_ce == 0.f;
+        const float kd = dflt ? 0.5f : P_.k_dice, kc = dflt ? 0.5f : P_.k_ce;
         float dz[C], dp[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) { dz[c] = 0.f; dp[c] = 0.f; }
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void mix_loss_bwd_kernel(const chap_mix_loss_p
         for (int c = 0; c < C; ++c) dot += dp[c] * p[c];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float gz = 0.5f * P_.gscale * (dz[c] + p[c] * (dp[c] - dot));
+            const float gz = P_.gscale * (kc * dz[c] + kd * p[c] * (dp[c] - dot));
             float* o = P_.dlogits + n * C * P + c * P + pp;
             *o = P_.accumulate ? *o + gz : gz;
         }
@@ -127,19 +129,21 @@ __global__ __launch_bounds__(256) void mix_loss_bwd_kernel(const chap_mix_loss_p
 static int loss_blocks(long total) { long b = (total + 255) / 256; return (int)(b < 2048 ? b : 2048); }
 
 extern "C" int chap_mix_loss_fwd(const chap_mix_loss_params* p, void* stream) {
-    CHAP_CHECK_ARG(p && p->logits && p->target_a && p->target_b && p->mask && p->acc && p->loss, "chap_mix_loss_fwd: null argument");
+    CHAP_CHECK_ARG(p && p->logits && p->target_a && p->acc && p->loss, "chap_mix_loss_fwd: null argument");
     CHAP_CHECK_ARG(p->C == 4 || p->C == 2, "chap_mix_loss: C=%d (2 or 4 built)", p->C);
     const int nb = loss_blocks((long)p->N * p->P);
     hipStream_t s = (hipStream_t)stream;
     if (p->C == 4) hipLaunchKernelGGL(mix_loss_acc_kernel<4>, dim3(nb), dim3(256), 0, s, *p);
     else hipLaunchKernelGGL(mix_loss_acc_kernel<2>, dim3(nb), dim3(256), 0, s, *p);
     CHAP_LAUNCH_CHECK("chap_mix_loss_fwd");
-    hipLaunchKernelGGL(mix_loss_final_kernel, dim3(1), dim3(64), 0, s, (const float*)p->acc, p->loss, p->C, p->w_a, p->w_b, p->smooth);
+    const bool dflt = p->k_dice == 0.f && p->k_ce == 0.f;
+    hipLaunchKernelGGL(mix_loss_final_kernel, dim3(1), dim3(64), 0, s, (const float*)p->acc, p->loss, p->C, p->w_a, p->w_b, p->smooth,
+                       dflt ? 0.5f : p->k_dice, dflt ? 0.5f : p->k_ce);
     CHAP_LAUNCH_CHECK("chap_mix_loss_fwd(final)");
     return CHAP_OK;
 }
 extern "C" int chap_mix_loss_bwd(const chap_mix_loss_params* p, void* stream) {
-    CHAP_CHECK_ARG(p && p->logits && p->target_a && p->target_b && p->mask && p->acc && p->dlogits, "chap_mix_loss_bwd: null argument");
+    CHAP_CHECK_ARG(p && p->logits && p->target_a && p->acc && p->dlogits, "chap_mix_loss_bwd: null argument");
     CHAP_CHECK_ARG(p->C == 4 || p->C == 2, "chap_mix_loss: C=%d (2 or 4 built)", p->C);
     const int nb = loss_blocks((long)p->N * p->P);
     if (p->C == 4) hipLaunchKernelGGL(mix_loss_bwd_kernel<4>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);

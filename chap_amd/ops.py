@@ -231,26 +231,27 @@ def cl_to_planar(lazy, out):
 
 # ------------------------------------------------------------------------------------------
 # losses / training-loop helpers (fp32 planar logits [N, C, *spatial])
-def mix_loss_fwd(logits, target_a, target_b, mask, w_a, w_b, smooth=1e-10):
-    """Returns (loss[3] = (loss_a, loss_b, total), acc) -- acc is needed by mix_loss_bwd."""
+def mix_loss_fwd(logits, target_a, target_b, mask, w_a, w_b, smooth=1e-10, k_dice=0.0, k_ce=0.0):
+    """Returns (loss[3] = (loss_a, loss_b, total), acc) -- acc is needed by mix_loss_bwd.
+    target_b / mask may be None (mask of ones); (k_dice, k_ce) = (0, 0) selects mix_loss's 0.5 / 0.5."""
     N, Cc = logits.shape[0], logits.shape[1]
     p = L.MixLossParams()
     acc = torch.zeros(2 * (2 + 3 * Cc), dtype=torch.float32, device=logits.device)
     loss = torch.empty(3, dtype=torch.float32, device=logits.device)
-    p.logits, p.target_a, p.target_b, p.mask = logits.data_ptr(), target_a.data_ptr(), target_b.data_ptr(), mask.data_ptr()
+    p.logits, p.target_a, p.target_b, p.mask = logits.data_ptr(), target_a.data_ptr(), _p(target_b), _p(mask)
     p.w_a, p.w_b, p.acc, p.loss = w_a, w_b, acc.data_ptr(), loss.data_ptr()
-    p.N, p.C, p.P, p.smooth = N, Cc, logits[0, 0].numel(), smooth
+    p.N, p.C, p.P, p.smooth, p.k_dice, p.k_ce = N, Cc, logits[0, 0].numel(), smooth, k_dice, k_ce
     L.call("chap_mix_loss_fwd", p, _stream())
     return loss, acc
 
 
-def mix_loss_bwd(logits, target_a, target_b, mask, w_a, w_b, acc, dlogits, gscale=1.0, accumulate=False, smooth=1e-10):
+def mix_loss_bwd(logits, target_a, target_b, mask, w_a, w_b, acc, dlogits, gscale=1.0, accumulate=False, smooth=1e-10, k_dice=0.0, k_ce=0.0):
     N, Cc = logits.shape[0], logits.shape[1]
     p = L.MixLossParams()
-    p.logits, p.target_a, p.target_b, p.mask = logits.data_ptr(), target_a.data_ptr(), target_b.data_ptr(), mask.data_ptr()
+    p.logits, p.target_a, p.target_b, p.mask = logits.data_ptr(), target_a.data_ptr(), _p(target_b), _p(mask)
     p.w_a, p.w_b, p.acc, p.dlogits = w_a, w_b, acc.data_ptr(), dlogits.data_ptr()
     p.gscale, p.accumulate = gscale, int(accumulate)
-    p.N, p.C, p.P, p.smooth = N, Cc, logits[0, 0].numel(), smooth
+    p.N, p.C, p.P, p.smooth, p.k_dice, p.k_ce = N, Cc, logits[0, 0].numel(), smooth, k_dice, k_ce
     L.call("chap_mix_loss_bwd", p, _stream())
 
 

@@ -334,3 +334,51 @@ class ChapStep:
             self._graph_opt.replay()
         self.finish()
         return self._static_out
+
+
+class AblationStep(ChapStep):
+    """One iteration of the ablation loop (train_ablation_2D.py:159-246): ONE full-batch forward, supervised
+    0.5*(CE + Dice) of both heads on the labeled half (:171-176), cross pseudo supervision -- CE of each head against
+    the other head's arg-max -- on the unlabeled half (:203-207,216-217), the same create_maskV1 + VAT2d pair as the main
+    loop (:228-230) and  loss = model1_loss + model2_loss + cw * (w_adv * vat_loss + w_drop * fp_loss)  (:236), then
+    SGD + poly LR.  `losses.DiceLoss` is absent upstream: the SSL4MIS definition (1 - (2 sum p t + s)/(sum p^2 + sum t +
+    s), s = 1e-5, mean over classes) is used.  The shipped VAT call passes the full-batch soft outputs next to an
+    unlabeled-half mask (shape-inconsistent); here, as in the main loop, VAT acts on the unlabeled half.  fp_loss (the
+    `dropout` branch, :209-213) is 0 as upstream.  Eager only (the consistency weight is applied from the host)."""
+
+    def device_step(self, volume_batch, label_batch, inject=None, update=True):
+        a, model = self.args, self.model
+        inject = inject or {}
+        lbs = a["labeled_bs"]
+        cw = get_current_consistency_weight(self.iter_num // 150, a)
+        out1, out2 = model(volume_batch, drop_masks=inject.get("drop_F"))
+        with torch.no_grad():
+            soft1, soft2, arg1, arg2, knowledge = ops.pseudo_block(out1[lbs:].contiguous(), out2[lbs:].contiguous())
+        d1, d2 = torch.empty_like(out1), torch.empty_like(out2)
+        lab = label_batch[:lbs].contiguous()
+        sup, cps = [], []
+        for o, d, other in ((out1, d1, arg2), (out2, d2, arg1)):
+            ol, ou = o[:lbs].contiguous(), o[lbs:].contiguous()
+            dl, du = torch.empty_like(ol), torch.empty_like(ou)
+            l3, acc = ops.mix_loss_fwd(ol, lab, None, None, 1.0, 0.0, smooth=1e-5)            # 0.5*(CE + Dice)
+            ops.mix_loss_bwd(ol, lab, None, None, 1.0, 0.0, acc, dl, smooth=1e-5)
+            c3, acc2 = ops.mix_loss_fwd(ou, other, None, None, 1.0, 0.0, k_dice=0.0, k_ce=1.0)  # mean CE vs the other head
+            ops.mix_loss_bwd(ou, other, None, None, 1.0, 0.0, acc2, du, gscale=cw, k_dice=0.0, k_ce=1.0)
+            d[:lbs].copy_(dl); d[lbs:].copy_(du)
+            sup.append(l3[0:1]); cps.append(c3[0:1])
+        torch.autograd.backward([out1, out2], [d1, d2])
+        vat_loss = torch.zeros(1, dtype=torch.float32, device=volume_batch.device)
+        if a["adv_noise"]:
+            diff_mask = ops.diff_mask(arg1, arg2, knowledge, 4, a["topk1"])
+            self.cw_dev.fill_(cw * a.get("w_adv", 1.0))
+            vat_loss = self.adv_loss(model, volume_batch, soft1, soft2, diff_mask, a["adv_losstype"], weight_dev=self.cw_dev,
+                                     inject=inject, grad_buffer=self.grad2)
+        if update:
+            self.exchange_and_update()
+        return {"sup_losses": sup, "cps_losses": cps, "vat_loss": vat_loss, "consistency_weight": cw}
+
+    def prepare(self, box_yx=None):
+        pass                                     # no BCP box in this loop
+
+    def capture(self, *a, **k):
+        raise NotImplementedError("chap_amd: AblationStep runs eagerly (host-side consistency weight)")

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CHAP_ABI_VERSION 1
+#define CHAP_ABI_VERSION 2
 #define CHAP_ACT_BWD_REPS 32   /* replicas of the BN-backward partial sums (spreads float atomics) */
 
 enum { CHAP_F32 = 0, CHAP_BF16 = 1 };
@@ -255,6 +255,9 @@ typedef struct {
     float* dlogits;             /* [N][C][P] or NULL: d(total*gscale)/dlogits, accumulated (+=) if accumulate */
     float gscale; int32_t accumulate;
     int32_t N, C, P; float smooth;
+    /* Generalisation for the second caller (train_ablation_2D.py:171-176,216-217): loss_k = w_k * (k_dice*Dice_k +
+     * k_ce*CE_k); k_dice = k_ce = 0 selects mix_loss's 0.5 / 0.5.  mask == NULL: all ones; target_b == NULL: target_a. */
+    float k_dice, k_ce;
 } chap_mix_loss_params;
 int chap_mix_loss_fwd(const chap_mix_loss_params* p, void* stream);
 int chap_mix_loss_bwd(const chap_mix_loss_params* p, void* stream);

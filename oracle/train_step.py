@@ -235,4 +235,66 @@ def iteration(sd, moms, volume_batch, label_batch, box_yx, iter_num, lr, args=No
                 grads=dict(zip(names, grads)))
 
 
+def dice_loss_std(soft, target, n_classes, smooth=1e-5):
+    """losses.DiceLoss (ABSENT upstream; SSL4MIS definition, what train_ablation_2D.py:144,172-176 calls with
+    softmax inputs and label.unsqueeze(1)): per class 1 - (2 sum s t + eps)/(sum s^2 + sum t^2 + eps), mean over classes."""
+    loss = 0.0
+    for c in range(n_classes):
+        s = soft[:, c]
+        t = (target == c).to(soft.dtype)
+        inter = (s * t).sum()
+        loss = loss + (1.0 - (2.0 * inter + smooth) / ((s * s).sum() + (t * t).sum() + smooth))
+    return loss / n_classes
+
+
+def ablation_iteration(sd, moms, volume_batch, label_batch, iter_num, lr, args=None, inject=None, net=None):
+    """One iteration of the ablation loop (train_ablation_2D.py:159-246) on CPU: full-batch forward, supervised
+    0.5*(CE + Dice) per head on the labeled half (:171-176), cross pseudo supervision on the unlabeled half (:203-207,
+    216-217), create_maskV1 + VAT2d (:228-230; on the unlabeled half, see chap_amd.train.AblationStep), loss (:236),
+    SGD (:238-241).  inject: {'drop_F': masks of the full-batch forward, 'drop_V0'.., 'drop_VF', 'd0'}."""
+    from . import nets
+    a = dict(ORACLE_ARGS)
+    a.update(dict(w_adv=1.0, w_drop=1.0))
+    a.update(args or {})
+    inject = inject or {}
+    net = net or nets.dual_decoder_2d
+    nc, lbs = a["num_classes"], a["labeled_bs"]
+    out1, out2 = net(sd, volume_batch, train=True, drop=inject.get("drop_F"))
+    soft1, soft2 = torch.softmax(out1, dim=1), torch.softmax(out2, dim=1)
+    cw = consistency_weight(iter_num, a["consistency"], a["consistency_rampup"])
+    lab = label_batch[:lbs].long()
+    loss1 = 0.5 * (F.cross_entropy(out1[:lbs], lab) + dice_loss_std(soft1[:lbs], lab, nc))
+    loss2 = 0.5 * (F.cross_entropy(out2[:lbs], lab) + dice_loss_std(soft2[:lbs], lab, nc))
+    arg1 = torch.max(soft1[lbs:].detach(), dim=1)[1]
+    arg2 = torch.max(soft2[lbs:].detach(), dim=1)[1]
+    ps1 = F.cross_entropy(out1[lbs:], arg2.long(), reduction="none")
+    ps2 = F.cross_entropy(out2[lbs:], arg1.long(), reduction="none")
+    knowledge = (ps1 + ps2).detach()
+    model1_loss = loss1 + cw * ps1.mean()
+    model2_loss = loss2 + cw * ps2.mean()
+    if a["adv_noise"]:
+        diff = create_mask_v1(arg1, arg2, knowledge, 4, a["topk1"]).unsqueeze(1)
+        calls = {"k": 0}
+
+        def model_fn(xx):
+            k = calls["k"]
+            calls["k"] += 1
+            key = "drop_V%d" % k if k < a["vat_iters"] else "drop_VF"
+            return net(sd, xx, train=True, drop=inject.get(key), update_stats=False)
+
+        x_u = volume_batch[lbs:]
+        d0 = inject["d0"] if inject.get("d0") is not None else torch.rand(x_u.shape) - 0.5
+        vat_loss, _ = vat2d(model_fn, x_u, soft1[lbs:].detach(), soft2[lbs:].detach(), diff, d0, a["noise_mag"], a["epi"], a["vat_iters"], a["vat_sign"])
+    else:
+        vat_loss = torch.zeros(())
+    fp_loss = torch.zeros(())
+    loss = model1_loss + model2_loss + cw * (vat_loss * a["w_adv"] + fp_loss * a["w_drop"])
+    names = [k for k, v in sd.items() if v.is_floating_point() and v.requires_grad]
+    grads = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
+    grads = [g if g is not None else torch.zeros_like(sd[k]) for g, k in zip(grads, names)]
+    sgd_step([sd[k] for k in names], grads, [moms[k] for k in names], lr, a["momentum"], a["weight_decay"])
+    return dict(sup=[loss1.detach(), loss2.detach()], cps=[ps1.mean().detach(), ps2.mean().detach()], vat_loss=vat_loss.detach(),
+                loss=loss.detach(), consistency_weight=cw)
+
+
 from chap_amd.synthetic import synthetic_batch, synthetic_batch_3d  # noqa: E402,F401  (data generators live with the product: bench.py must not import oracle/ for data)

@@ -131,3 +131,48 @@ def test_iteration_3d_matches_oracle():
     cos = float(uh @ uo / (uh.norm() * uo.norm()))
     assert cos > 0.995, cos
     assert worst < 0.5, (worst, worst_key)
+
+
+def test_ablation_iteration_matches_oracle():
+    """The second caller of the same kernels (train_ablation_2D.py:159-246): full-batch forward, supervised CE+Dice,
+    cross pseudo supervision, create_maskV1 + VAT, SGD -- fp32 against the CPU oracle with injected randomness."""
+    from chap_amd.train import AblationStep
+    B, lbs, H, W = 8, 4, 64, 64
+    U = B - lbs
+    args = dict(labeled_bs=lbs, batch_size=B, vat_iters=1, w_adv=0.7)
+    state = oinit.dual_decoder_2d_state(404)
+    vol, lab = ots.synthetic_batch(4321, lbs, U, H, W)
+    inj_cpu = {"drop_F": oinit.drop_masks_2d(11, B, H, W), "drop_V0": oinit.drop_masks_2d(13, U, H, W), "drop_VF": oinit.drop_masks_2d(14, U, H, W),
+               "d0": torch.rand(U, 1, H, W, generator=torch.Generator().manual_seed(15)) - 0.5}
+    it0 = 3000                                                   # consistency weight exp(-5 * 0.6^2) = 0.165: the CPS / VAT terms matter
+    sd = {k: v.clone() for k, v in state.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    moms = {k: torch.zeros_like(v) for k, v in sd.items() if v.requires_grad}
+    ref = ots.ablation_iteration(sd, moms, vol, lab, iter_num=it0, lr=0.01, args=args, inject=inj_cpu)
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train()
+    m.load_state_dict(state, strict=True)
+    step = AblationStep(m, args)
+    step.iter_num = it0
+    inj = {k: (cl_masks(v) if k.startswith("drop") else v.to(DEV)) for k, v in inj_cpu.items()}
+    out = step.step(vol.to(DEV), lab.to(DEV), inject=inj)
+    torch.cuda.synchronize()
+    assert abs(out["consistency_weight"] - ref["consistency_weight"]) < 1e-12
+    for got, want in zip(out["sup_losses"] + out["cps_losses"], ref["sup"] + ref["cps"]):
+        assert relerr(got.cpu(), want.reshape(1)) < 2e-4
+    assert relerr(out["vat_loss"].cpu(), ref["vat_loss"].reshape(1)) < 5e-3
+    after = m.state_dict()
+    worst, worst_key = 0.0, None
+    for k, v in sd.items():
+        if not v.is_floating_point():
+            continue
+        d = (after[k].cpu().double() - v.detach().double()).abs().max().item()
+        upd = (v.detach().double() - state[k].double()).abs().max().item()
+        floor = 3e-7 * v.detach().abs().max().item()
+        if upd > 0 and max(d - floor, 0.0) / upd > worst:
+            worst, worst_key = max(d - floor, 0.0) / upd, k
+    assert worst < 0.05, (worst, worst_key)
+    assert step.iter_num == it0 + 1
+    with pytest.raises(NotImplementedError):
+        step.capture(vol.to(DEV), lab.to(DEV))
