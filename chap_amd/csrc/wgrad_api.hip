@@ -19,7 +19,8 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     const int TH = small_tile ? 4 : 8;
     q->ntiles = (long)p->N * p->D * cdiv(p->H, TH) * cdiv(p->W, 16);
     const long pairs = (long)(q->Ca / q->KC) * cdiv(q->Cb, q->Cb <= 16 ? 16 : 32);
-    long ns = 512 / pairs;       // persistent, pipelined blocks: ~2 per CU are enough; fewer splits = fewer slab bytes to reduce
+    long ns = 256 / pairs;       // persistent, pipelined blocks: about one per CU (measured on the whole iteration: 64 / 128 / 192 / 256 / 384 / 512 /
+                                 // 1024 target blocks -> 9.4 / 7.9 / 7.6 / 7.5 / 7.7 / 7.8 / 8.1 ms per 2D step); fewer splits = fewer slab bytes to reduce
     if (ns < 1) ns = 1;
     if (ns > q->ntiles) ns = q->ntiles;
     q->slab = (size_t)q->taps * q->Ca * q->Cb * sizeof(float);
