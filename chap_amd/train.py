@@ -121,8 +121,15 @@ class ChapStep:
         self.adv_loss = VAT2d(xi=a["noise_mag"], epi=a["epi"], num_classes=a["num_classes"], ip=a["vat_iters"], sign=a["vat_sign"])
         dev = self.opt.lr_dev.device
         self.dims = getattr(model, "dims", 2)
-        self.box = torch.zeros(4 if self.dims == 2 else 6, dtype=torch.int32, device=dev)
-        self.cw_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        # host-scheduled values of an iteration in ONE device word block -> one host-to-device copy per step:
+        # [BCP box: 4 / 6 int32 | consistency weight f32 | learning rate f32]
+        nbox = 4 if self.dims == 2 else 6
+        self._sched = torch.zeros(8, dtype=torch.int32, device=dev)
+        self.box = self._sched[:nbox]
+        self.cw_dev = self._sched[6:7].view(torch.float32)
+        if isinstance(self.opt, FusedSGD):                       # the optimizer reads its lr from the same block
+            self._sched[7:8].view(torch.float32).copy_(self.opt.lr_dev)
+            self.opt.lr_dev = self._sched[7:8].view(torch.float32)
         self.iter_num = 0
         self.world_size = world_size
         self.grad_sync = None                   # parallel.DataParallelSync (world_size > 1)
@@ -150,15 +157,23 @@ class ChapStep:
         sizes = [int(s * 2 / 3) for s in self._hw]                 # patch = 2/3 of every side (:96)
         if box_yx is None:
             box_yx = tuple(np.random.randint(0, s - p) for s, p in zip(self._hw, sizes))
-        self.box.copy_(torch.tensor(list(box_yx) + sizes, dtype=torch.int32))
-        self.cw_dev.fill_(get_current_consistency_weight(self.iter_num // 150, a))
+        self._upload_sched(list(box_yx) + sizes, get_current_consistency_weight(self.iter_num // 150, a))
+
+    def _upload_sched(self, box_vals, cw):
+        import struct
+        f2i = lambda v: struct.unpack("<i", struct.pack("<f", float(v)))[0]
+        vals = list(box_vals) + [0] * (6 - len(box_vals)) + [f2i(cw), f2i(self.opt.param_groups[0]["lr"])]
+        self._sched.copy_(torch.tensor(vals, dtype=torch.int32))
 
     def finish(self):
         """poly LR applied AFTER the step (train_ours_2D.py:385-389)."""
         a = self.args
         self.iter_num += 1
         lr_ = a["base_lr"] * (1.0 - self.iter_num / a["max_iterations"]) ** 0.9
-        self.opt.set_lr(lr_)
+        if isinstance(self.opt, FusedSGD):
+            self.opt.param_groups[0]["lr"] = float(lr_)          # reaches the device with the next step's schedule block
+        else:
+            self.opt.set_lr(lr_)
         return lr_
 
     # ------------------------------------------------------------------ checkpoint / resume (build extension, SURVEY N4)
@@ -378,7 +393,7 @@ class AblationStep(ChapStep):
         return {"sup_losses": sup, "cps_losses": cps, "vat_loss": vat_loss, "consistency_weight": cw}
 
     def prepare(self, box_yx=None):
-        pass                                     # no BCP box in this loop
+        self._upload_sched([], 0.0)              # no BCP box in this loop; device_step sets the (w_adv-scaled) weight itself
 
     def capture(self, *a, **k):
         raise NotImplementedError("chap_amd: AblationStep runs eagerly (host-side consistency weight)")
