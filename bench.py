@@ -168,8 +168,15 @@ def dominant_kernel_roofline_3d(dtype, N, sp):
     esz = 2 if dtype == torch.bfloat16 else 4
     alg_bytes = 2.0 * N * D * H * W * 16 * esz
     ach = alg_bytes / (us * 1e-6) / 1e9
+    kname = "conv_fwd_kernel<%s,3,1,3D,KC16,NT1> 16->16 @%dx%dx%d N=%d" % ("bf16" if esz == 2 else "f32", D, H, W, N)
+    traffic = None                 # HBM bytes per launch from the committed rocprofv3 --pmc passes (same kernel, same shape)
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")))
+        traffic = pmc[kname]["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     return {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "traffic": None, "kernel": "conv_fwd_kernel<%s,3,1,3D,KC16,NT1> 16->16 @%dx%dx%d N=%d" % ("bf16" if esz == 2 else "f32", D, H, W, N),
+            "traffic": traffic, "kernel": kname,
             "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": alg_bytes}
 
 

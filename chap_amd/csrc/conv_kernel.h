@@ -444,10 +444,14 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     // tile walk: tiles t_first, t_first + 1, ...: the (x, y, z, n) tile coordinates advance by +1 with carries
     int ntx = 0, nty = 0, ntz = 0, nn = 0;                      // tile coordinates of the item being prefetched
     {
+        // 3D: z runs fastest -- consecutive bricks of a run share 2 of their 6 halo planes (x neighbours: 2 of 18 columns),
+        // and the x / y neighbours are only tiles_z bricks away, i.e. still in this XCD's L2 (measured on the 16->16 layer at
+        // 112x112x80: FETCH_SIZE 1.95x the algorithmic read with x fastest)
         unsigned t = t_first;
+        if (D3) { ntz = t % (unsigned)tiles_z; t /= (unsigned)tiles_z; }
         ntx = t % (unsigned)tiles_x; t /= (unsigned)tiles_x;
         nty = t % (unsigned)tiles_y; t /= (unsigned)tiles_y;
-        ntz = t % (unsigned)tiles_z; nn = t / (unsigned)tiles_z;
+        if (D3) nn = t; else { ntz = t % (unsigned)tiles_z; nn = t / (unsigned)tiles_z; }
     }
     if (nitems > 0)
         halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW, ONE>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, ntz * G::TD, nty * G::TH, ntx * G::TW, 0, lanesel);
@@ -620,10 +624,11 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
         if (has_next) {
             if (nchunk == nchunks) {
                 nchunk = 0;
-                ntx += 1; int c = ntx >= tiles_x; ntx -= c ? tiles_x : 0;
+                int c = 1;
+                if (D3) { ntz += 1; c = ntz >= tiles_z; ntz -= c ? tiles_z : 0; }
+                ntx += c; c = ntx >= tiles_x; ntx -= c ? tiles_x : 0;
                 nty += c; c = nty >= tiles_y; nty -= c ? tiles_y : 0;
-                ntz += c; c = ntz >= tiles_z; ntz -= c ? tiles_z : 0;
-                nn += c;
+                if (D3) nn += c; else { ntz += c; c = ntz >= tiles_z; ntz -= c ? tiles_z : 0; nn += c; }
             }
             halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW, ONE>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, ntz * G::TD, nty * G::TH, ntx * G::TW, nchunk, lanesel);
             wstage_issue(nchunk);

@@ -7,6 +7,8 @@ import torch
 import bench
 
 if __name__ == "__main__":
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-    r = bench.dominant_kernel_roofline(None, torch.bfloat16, n, 256)
-    print(r)
+    if len(sys.argv) > 1 and sys.argv[1] == "3d":            # the 3D bench's roofline kernel: 16->16 3x3x3 at 112x112x80, N = 2
+        print(bench.dominant_kernel_roofline_3d(torch.bfloat16, 2, (112, 112, 80)))
+    else:
+        n = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+        print(bench.dominant_kernel_roofline(None, torch.bfloat16, n, 256))
