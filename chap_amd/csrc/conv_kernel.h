@@ -422,6 +422,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     const long my_tiles = (long)(tq + ((unsigned)bix < trem ? 1u : 0u));
     const long nitems = my_tiles * nchunks;
 
+    CHAP_STAMP_P(6);
     // ---- one-time per thread: unit descriptors, MFMA fragment offsets ----
     unit_desc<UNITS> U;
     make_units<G, GPT, PS, UNITS>(U, P.IH, P.IW);
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
                                   : ((dz * G::HH + (wave * MR) * ST + dy) * G::HW + px * ST + dx) * PS + cgl * 8) : -1;
     }
 
+    CHAP_STAMP_P(7);
     // ---- one-time per block.  Every global load of the prologue (first halo, scale/shift, resident weights,
     // bias) is issued before the first dependent LDS store, so that the block pays ONE memory round trip before
     // its first tile instead of four in a row (a block only owns a handful of tiles: this is a large part of

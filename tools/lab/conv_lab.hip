@@ -64,7 +64,7 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
             hipMemcpyFromSymbol(hp, HIP_SYMBOL(chap_trace_p), sizeof(hp));
             unsigned long long t0 = hp[0][0][0];
             for (int b = 0; b < 4; ++b) { unsigned long long* r = hp[b][0];
-                printf("  block %d: start %+.2f | loads issued %.2f | barrier %.2f | first commit %.2f | item loop %.2f | stats flush %.2f | total %.2f\n", b * 257, ((double)r[0] - (double)t0) / 100., (r[1]-r[0])/100., (r[2]-r[1])/100., (r[3]-r[2])/100., (r[4]-r[3])/100., (r[5]-r[4])/100., (r[5]-r[0])/100.); }
+                printf("  block %d: start %+.2f | setup %.2f units+xoff %.2f rest-to-loads-issued %.2f | loads issued %.2f | barrier %.2f | first commit %.2f | item loop %.2f | stats flush %.2f | total %.2f\n", b * 257, ((double)r[0] - (double)t0) / 100., (r[6]-r[0])/100., (r[7]-r[6])/100., (r[1]-r[7])/100., (r[1]-r[0])/100., (r[2]-r[1])/100., (r[3]-r[2])/100., (r[4]-r[3])/100., (r[5]-r[4])/100., (r[5]-r[0])/100.); }
         }
 #endif
         printf("mw=%d abl=%2d %-28s occ=%d grid=%5ldx%d lds=%6zu : %8.1f us %7.1f GB/s\n", CHAP_CONV_MINWAVES, CHAP_ABLATE, name, occ, gx, gy, lds, us, gb);
