@@ -196,6 +196,9 @@ _SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParam
 _lib = None
 
 
+ABI_VERSION = 2            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
+
+
 class ChapError(RuntimeError):
     pass
 

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 35
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.chap_abi_version() == 2
+    assert lib.chap_abi_version() == _lib.ABI_VERSION == 2
     # every entry point bound in the ctypes tables is declared in the header and vice versa
     bound = set(_lib._SIGS) | set(_lib._SIZE_FNS) | {"chap_last_error", "chap_abi_version", "chap_debug_copy", "chap_pack_describe", "chap_pack_multi"}
     assert bound == set(names), (bound ^ set(names))
@@ -130,3 +130,9 @@ def test_host_schedules_match_oracle():
         assert abs(train.get_current_consistency_weight(it // 150, train.DEFAULT_ARGS) - ots.consistency_weight(it)) < 1e-12
     assert train.sigmoid_rampup(0, 0) == 1.0 and abs(train.sigmoid_rampup(50, 50) - 1.0) < 1e-12
     assert abs(train.sigmoid_rampup(0, 50) - np.exp(-5.0)) < 1e-12
+
+
+def test_graft_entry_build():
+    """The driver's build check: compiles (no-op when up to date), loads the library and checks the ABI version."""
+    import __graft_entry__ as g
+    g.build()
