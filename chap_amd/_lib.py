@@ -210,6 +210,16 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ChapError("libchap_hip.so not built (%s missing): run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "or `make -C chap_amd/csrc`.  chap_amd has no CPU fallback." % LIB_PATH)
+        # The library is linked against the system ROCm runtime while PyTorch ships its own copy: the HIP runtime
+        # PyTorch uses has to be initialised BEFORE this library is loaded (observed on the MI355X box: loaded the
+        # other way round, the first kernel launch fails with "no ROCm-capable device is detected").
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+                torch.cuda.current_stream()
+        except Exception:
+            pass
         L = C.CDLL(LIB_PATH)
         L.chap_last_error.restype = C.c_char_p
         L.chap_abi_version.restype = C.c_int
