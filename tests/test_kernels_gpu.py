@@ -282,3 +282,35 @@ def test_pool_upsample_bnfinalize(dtype):
     got = y * scale.cpu().view(1, C, 1, 1) + shift.cpu().view(1, C, 1, 1)
     assert relerr(got, ref) < 1e-5
     assert relerr(rmd, rm_ref) < 1e-5 and relerr(rvd, rv_ref) < 1e-5 and int(nbt) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,c,add2", [((3, 10, 14, 14), 128, False), ((2, 9, 13, 20), 32, False), ((2, 12, 18, 30), 16, False),
+                                          ((3, 10, 14, 14), 64, True), ((2, 11, 15, 34), 32, True)])
+def test_conv3d_bricks_ragged(dtype, shape, c, add2):
+    """3x3x3 conv on grids that are NOT multiples of the 4 x 4 x 16 brick (the V-Net's 14x14x10 / 7x7x5 levels), large
+    enough (>= 32 bricks) to take the z-per-wave brick kernels (bf16) -- lazy BN/ReLU source, Dropout3d channel
+    multipliers, optional skip add, bias, BatchNorm statistics."""
+    g = torch.Generator().manual_seed(11)
+    N, D, H, W = shape
+    x0 = rq(torch.randn(N, c, D, H, W, generator=g), dtype)
+    sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+    cm = (torch.rand(N, c, generator=g) > 0.3).float() * 1.5
+    w = torch.randn(c, c, 3, 3, 3, generator=g) / (c * 27) ** 0.5
+    b = torch.randn(c, generator=g) * 0.1
+    a = lazy_ref(x0, sc, sh, 0.0, None, 1.0) * cm.view(N, c, 1, 1, 1)
+    srcs = [ops.Lazy(cl(x0, dtype), sc.to(DEV), sh.to(DEV), True, 0.0, chan_mul=cm.to(DEV))]
+    if add2:
+        x1 = rq(torch.randn(N, c, D, H, W, generator=g), dtype)
+        a = a + x1
+        srcs.append(ops.Lazy(cl(x1, dtype)))
+    ref = F.conv3d(rq(a, dtype), rq(w, dtype), b, padding=1)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, c, c, 27)
+    out = torch.empty(N, D, H, W, c, device=DEV, dtype=dtype)
+    stats = torch.zeros(8, 2, c, device=DEV)
+    ops.conv_fwd(srcs, wp, b.to(DEV), c, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=3,
+                 combine=1 if add2 else 0, stats=stats, stats_reps=8)
+    assert relerr(uncl(out), ref) < 2 * TOL[dtype]
+    st = stats.sum(0).cpu()
+    assert relerr(st[0], ref.sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
+    assert relerr(st[1], (ref * ref).sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
