@@ -255,3 +255,32 @@ def test_lcc_and_box_3d():
     kn = torch.rand(N, D, H, W, generator=g) * 3
     p1, p2 = lab, torch.roll(lab, 1, 3)
     assert (ops.diff_mask(p1.to(DEV), p2.to(DEV), kn.to(DEV), 4, 0.1).cpu() == ots.create_mask_v1(p1, p2, kn, 4, 0.1)).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape,cin,cout,add2", [((2, 10, 14, 14), 32, 32, False), ((1, 9, 13, 20), 16, 16, False), ((2, 5, 7, 7), 64, 128, False),
+                                                 ((1, 10, 14, 14), 32, 16, True)])
+def test_wgrad_conv3d_ragged(dtype, shape, cin, cout, add2):
+    """3x3x3 weight gradient on ragged grids (the V-Net's 14x14x10 / 7x7x5 levels): lazy BN/ReLU A operand with
+    Dropout3d multipliers, optional skip add, 16- and 32-wide B tiles, bias gradient, accumulation into existing dW."""
+    g = torch.Generator().manual_seed(21)
+    N, D, H, W = shape
+    x = rq(torch.randn(N, cin, D, H, W, generator=g), dtype)
+    gy = rq(torch.randn(N, cout, D, H, W, generator=g), dtype)
+    sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.2
+    cm = (torch.rand(N, cin, generator=g) > 0.3).float() * 1.5
+    a = lazy_ref(x, sc, sh, 0.0, None, 1.0) * cm.view(N, cin, 1, 1, 1)
+    srcs = [ops.Lazy(cl(x, dtype), sc.to(DEV), sh.to(DEV), True, 0.0, chan_mul=cm.to(DEV))]
+    if add2:
+        x1 = rq(torch.randn(N, cin, D, H, W, generator=g), dtype)
+        a = a + x1
+        srcs.append(ops.Lazy(cl(x1, dtype)))
+    w = torch.zeros(cout, cin, 3, 3, 3, requires_grad=True)
+    F.conv3d(rq(a, dtype), w, None, padding=1).backward(gy)
+    dw = torch.full((cout, cin, 3, 3, 3), 0.25, device=DEV)
+    db = torch.zeros(cout, device=DEV)
+    ops.wgrad(srcs, ops.Lazy(cl(gy, dtype)), dw, (1, 27, cin * 27), grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=3,
+              combine=1 if add2 else 0, db=db)
+    tol = 1e-4 if dtype == torch.float32 else 2e-2
+    assert relerr(dw - 0.25, w.grad) < tol
+    assert relerr(db, gy.sum((0, 2, 3, 4))) < tol
