@@ -314,3 +314,30 @@ def test_conv3d_bricks_ragged(dtype, shape, c, add2):
     st = stats.sum(0).cpu()
     assert relerr(st[0], ref.sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
     assert relerr(st[1], (ref * ref).sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,hw,cin,cout", [(4, (250, 254), 16, 16), (12, (62, 66), 64, 64), (12, (30, 34), 128, 128), (6, (126, 130), 32, 16)])
+def test_conv3x3_2d_bench_shapes_ragged(dtype, N, hw, cin, cout):
+    """The blockings the bench actually runs (16x16-pixel tiles with resident weights, 8x16 tiles x 32 channels with
+    staged weights, ...) on grids that are NOT multiples of the tile: lazy BN/LeakyReLU source with a Dropout keep mask,
+    bias, BatchNorm statistics."""
+    g = torch.Generator().manual_seed(31)
+    H, W = hw
+    x = rq(torch.randn(N, cin, H, W, generator=g), dtype)
+    sc, sh = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.2
+    keep = (torch.rand(N, cin, H, W, generator=g) > 0.2).float()
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    a = lazy_ref(x, sc, sh, 0.01, keep, 1.25)
+    ref = F.conv2d(rq(a, dtype), rq(w, dtype), b, padding=1)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, cin, cout, 9)
+    out = torch.empty(N, 1, H, W, cout, device=DEV, dtype=dtype)
+    stats = torch.zeros(8, 2, cout, device=DEV)
+    km = keep.permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(DEV, torch.uint8)
+    src = ops.Lazy(cl(x, dtype), sc.to(DEV), sh.to(DEV), True, 0.01, keep=km, keep_scale=1.25)
+    ops.conv_fwd([src], wp, b.to(DEV), cout, out, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2, stats=stats, stats_reps=8)
+    assert relerr(uncl(out).squeeze(2), ref) < 2 * TOL[dtype]
+    st = stats.sum(0).cpu()
+    assert relerr(st[0], ref.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
+    assert relerr(st[1], (ref * ref).sum((0, 2, 3))) < 1e-3 + TOL[dtype]
