@@ -285,22 +285,6 @@ __device__ __forceinline__ void keep8(float v[8], uint2 keep, float keep_scale) 
     }
 }
 
-// one-shot variant (reads scale/shift from the LDS cache) for operands staged once per tile
-__device__ __forceinline__ void lazy_transform(float v[8], const float* aff, int c, float slope_eff, bool has_keep, uint2 keep, float keep_scale,
-                                               const float* cm) {
-    f32x2 a[4], b[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { a[k] = *(const f32x2*)(aff + c + 2 * k); b[k] = *(const f32x2*)(aff + CONV_MAX_AFFINE_C / 2 + c + 2 * k); }
-    affine_act8(v, a, b, slope_eff);
-    if (has_keep) keep8(v, keep, keep_scale);
-    if (cm) {
-        float m[8];
-        ld8(cm + c, m);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= m[j];
-    }
-}
-
 template <typename T, int KC, bool ADD2, int UNITS, bool LANESEL, bool KEEPM, bool ONE>
 __device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2, KEEPM>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
                                                  const float* aff, bool plain, int n, int chunk) {
