@@ -155,6 +155,16 @@ class ChanMaskParams(C.Structure):
     _fields_ = [("mul", _vp), ("seed", C.c_uint64), ("seed_dev", _vp), ("n", _i64), ("p", _f32)]
 
 
+class SampleChanSumParams(C.Structure):
+    _fields_ = [("r", Src), ("partial", _vp), ("N", _i32), ("nchunk", _i32), ("pix_per_sample", _i64), ("dtype", _i32)]
+
+
+class ChannelDropParams(C.Structure):
+    _fields_ = [("pool_partial", _vp), ("grad_sim", _vp), ("u1", _vp), ("u2", _vp), ("mul1", _vp), ("mul2", _vp),
+                ("probs_out", _vp), ("inv_npix", _f32), ("nchunk", _i32), ("B", _i32), ("U", _i32), ("C", _i32),
+                ("mode", _i32), ("comp", _i32), ("branch", _i32), ("prob_kind", _i32)]
+
+
 class BoxMixParams(C.Structure):
     _fields_ = [("a", _vp), ("b", _vp), ("out", _vp), ("box", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("is_i64", _i32), ("D", _i32)]
 
@@ -189,6 +199,7 @@ _SIGS = {  # name -> (restype, params struct or None)
     "chap_rand_uniform": RandParams, "chap_keep_mask": KeepMaskParams, "chap_chan_mask": ChanMaskParams,
     "chap_box_mix": BoxMixParams, "chap_box_mask": BoxMaskParams, "chap_largest_cc": LccParams,
     "chap_diff_mask": DiffMaskParams, "chap_sgd_step": SgdParams,
+    "chap_sample_channel_sum": SampleChanSumParams, "chap_channel_drop": ChannelDropParams,
 }
 _SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParams, "chap_wgrad_ws": WgradParams,
              "chap_lcc_ws": LccParams}
@@ -196,7 +207,7 @@ _SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParam
 _lib = None
 
 
-ABI_VERSION = 2            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
+ABI_VERSION = 3            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
 
 
 class ChapError(RuntimeError):

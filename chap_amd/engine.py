@@ -154,7 +154,7 @@ class Executor:
         return self._ensure_packed(dtype, sd)["bufs"][(op.w, kind)]
 
     # ---------------------------------------------------------------- forward
-    def forward(self, x, *, train, dtype, save, update_stats=True, drop_masks=None, rng=None, want=()):
+    def forward(self, x, *, train, dtype, save, update_stats=True, drop_masks=None, rng=None, want=(), perturb=None):
         """x: fp32 [N, 1, *spatial] contiguous. Returns (list of planar fp32 logits, Saved|None, extras):
         extras = the activated values named in `want`, materialised as planar fp32 [N, C, *spatial]."""
         prog, sd, dims = self.prog, self._sd(), self.prog.dims
@@ -184,45 +184,45 @@ class Executor:
         branches = sorted({op.branch for op in prog.ops})
         side = self._side_stream(cur_stream) if len(branches) > 2 else None
 
-        def run_op(op):
+        def run_op(op, V=vals, n=N):      # V / n: value table and batch size (the decoders of a perturbed pass see their own)
             nonlocal apos
             k = op.kind
             if k == "pool":
-                src = vals[op.srcs[0]]
+                src = V[op.srcs[0]]
                 d, h, w = vdims[op.srcs[0]]
                 od = d // 2 if dims == 3 else 1
-                out = torch.empty(N, od, h // 2, w // 2, src.C, dtype=dtype, device=dev)
-                idx = torch.empty(N, od, h // 2, w // 2, src.C, dtype=torch.uint8, device=dev) if save else None
+                out = torch.empty(n, od, h // 2, w // 2, src.C, dtype=dtype, device=dev)
+                idx = torch.empty(n, od, h // 2, w // 2, src.C, dtype=torch.uint8, device=dev) if save else None
                 ops.act_pool2(src, out, idx, dims=dims)
-                vals[op.out], vdims[op.out] = Lazy(out), (od, h // 2, w // 2)
+                V[op.out], vdims[op.out] = Lazy(out), (od, h // 2, w // 2)
                 if save:
                     S.pool_idx[op.out] = idx
                 return
             if k == "up":
-                src = vals[op.srcs[0]]
+                src = V[op.srcs[0]]
                 d, h, w = vdims[op.srcs[0]]
                 od = 2 * d if dims == 3 else d
-                out = torch.empty(N, od, 2 * h, 2 * w, src.C, dtype=dtype, device=dev)
+                out = torch.empty(n, od, 2 * h, 2 * w, src.C, dtype=dtype, device=dev)
                 ops.upsample2x(src, out, dims=dims, half_pixel=op.half_pixel)
-                vals[op.out], vdims[op.out] = Lazy(out), (od, 2 * h, 2 * w)
+                V[op.out], vdims[op.out] = Lazy(out), (od, 2 * h, 2 * w)
                 return
             # ---- convolutions
             stats = take(STATS_REPS * 2 * op.cout) if ((op.bn and train) or op.inorm) else None
             bias = sd[op.b] if op.b else None
             if k == "c1":
                 gd = (D, H, W)
-                out = torch.empty(N, D, H, W, op.cout, dtype=dtype, device=dev)
+                out = torch.empty(n, D, H, W, op.cout, dtype=dtype, device=dev)
                 if dtype == torch.bfloat16:
-                    xpad = torch.empty(N, D, H, W, 16, dtype=dtype, device=dev)
+                    xpad = torch.empty(n, D, H, W, 16, dtype=dtype, device=dev)
                     ops.planar_to_cl(x, xpad, cpad=16)
                     S.xpad = xpad
                     wp = self._pack(op, L.PACK_CONV_FWD, dtype, sd)
-                    ops.conv_fwd([Lazy(xpad)], wp, bias, op.cout, out, grid=(N,) + gd, in_dims=gd, ksize=3, stride=1, dims=dims,
+                    ops.conv_fwd([Lazy(xpad)], wp, bias, op.cout, out, grid=(n,) + gd, in_dims=gd, ksize=3, stride=1, dims=dims,
                                  stats=stats, stats_reps=STATS_REPS)
                 else:
-                    ops.conv_c1_fwd(x.view(N, D, H, W), sd[op.w], bias, out, dims=dims, stats=stats, stats_reps=STATS_REPS)
+                    ops.conv_c1_fwd(x.view(n, D, H, W), sd[op.w], bias, out, dims=dims, stats=stats, stats_reps=STATS_REPS)
             else:
-                srcs = [vals[s] for s in op.srcs]
+                srcs = [V[s] for s in op.srcs]
                 sd_, sh_, sw_ = vdims[op.srcs[0]]
                 if k == "conv":
                     gd, ind, ks, st, kind = (sd_, sh_, sw_), (sd_, sh_, sw_), op.ksize, 1, L.PACK_CONV_FWD
@@ -233,21 +233,21 @@ class Executor:
                     gd, ind, ks, st, kind = (sd_, sh_, sw_), (sd_, sh_, sw_), 1, 1, L.PACK_DECONV_FWD
                 wp = self._pack(op, kind, dtype, sd)
                 if op.head:
-                    out = torch.empty((N, op.cout) + ((gd[1], gd[2]) if dims == 2 else gd), dtype=torch.float32, device=dev)
-                    ops.conv_fwd(srcs, wp, bias, op.cout, out, grid=(N,) + gd, in_dims=ind, ksize=ks, stride=st, dims=dims,
+                    out = torch.empty((n, op.cout) + ((gd[1], gd[2]) if dims == 2 else gd), dtype=torch.float32, device=dev)
+                    ops.conv_fwd(srcs, wp, bias, op.cout, out, grid=(n,) + gd, in_dims=ind, ksize=ks, stride=st, dims=dims,
                                  combine=op.combine, out_planar=True, out_f32=True)
                     outs[op.out] = out
                     vdims[op.out] = gd
                     return
                 if k == "deconv":
                     od = (2 * gd[0] if dims == 3 else gd[0], 2 * gd[1], 2 * gd[2])
-                    out = torch.empty((N,) + od + (op.cout,), dtype=dtype, device=dev)
-                    ops.conv_fwd(srcs, wp, bias, (2 ** dims) * op.cout, out, grid=(N,) + gd, in_dims=ind, ksize=1, stride=1, dims=dims,
+                    out = torch.empty((n,) + od + (op.cout,), dtype=dtype, device=dev)
+                    ops.conv_fwd(srcs, wp, bias, (2 ** dims) * op.cout, out, grid=(n,) + gd, in_dims=ind, ksize=1, stride=1, dims=dims,
                                  combine=op.combine, out_mode=1, out_cn=op.cout, stats=stats, stats_reps=STATS_REPS)
                     gd = od
                 else:
-                    out = torch.empty((N,) + gd + (op.cout,), dtype=dtype, device=dev)
-                    ops.conv_fwd(srcs, wp, bias, op.cout, out, grid=(N,) + gd, in_dims=ind, ksize=ks, stride=st, dims=dims,
+                    out = torch.empty((n,) + gd + (op.cout,), dtype=dtype, device=dev)
+                    ops.conv_fwd(srcs, wp, bias, op.cout, out, grid=(n,) + gd, in_dims=ind, ksize=ks, stride=st, dims=dims,
                                  combine=op.combine, stats=stats, stats_reps=STATS_REPS)
             vdims[op.out] = gd
             if op.inorm:            # InstanceNorm3d (affine=False) + ReLU: statistics of this single sample
@@ -261,7 +261,7 @@ class Executor:
                 scale, shift = take(op.cout), take(op.cout)
                 if train:
                     mean, invstd = take(op.cout), take(op.cout)
-                    cnt = N * gd[0] * gd[1] * gd[2]
+                    cnt = n * gd[0] * gd[1] * gd[2]
                     upd = update_stats
                     ops.bn_finalize(stats, STATS_REPS, sd[op.bn + ".weight"], sd[op.bn + ".bias"],
                                     sd[op.bn + ".running_mean"] if upd else None, sd[op.bn + ".running_var"] if upd else None,
@@ -288,29 +288,38 @@ class Executor:
                     if drop_masks is not None:
                         cm = drop_masks.get(site)
                     else:
-                        cm = torch.empty(N, op.cout, dtype=torch.float32, device=dev)
+                        cm = torch.empty(n, op.cout, dtype=torch.float32, device=dev)
                         ops.chan_mask(cm, rng.next_seed(), p, seed_dev=rng.seed_dev)
                     if cm is not None:
                         lz.chan_mul = cm
-            vals[op.out] = lz
+            V[op.out] = lz
         # ---- schedule: trunk, then the decoders side by side (second decoder on a forked stream)
         for op in prog.ops:
             if op.branch == 0:
                 run_op(op)
+        if perturb is not None:
+            # channel-level perturbation (FilterDropout.perform_dropout): every decoder gets its own version of the
+            # trunk's values -- a larger batch with per-(sample, channel) multipliers -- and runs on that batch
+            assert not save, "the perturbed pass is forward-only"
+            overlays, n_dec = perturb(vals, vdims)
+            tables = {b: dict(vals, **overlays[b]) for b in branches if b != 0}
+            run_dec = lambda op: run_op(op, tables[op.branch], n_dec)      # noqa: E731
+        else:
+            run_dec = run_op
         if side is not None:
             side.wait_stream(cur_stream)
             with torch.cuda.stream(side):
                 for op in prog.ops:
                     if op.branch >= 2:
-                        run_op(op)
+                        run_dec(op)
             for op in prog.ops:
                 if op.branch == 1:
-                    run_op(op)
+                    run_dec(op)
             cur_stream.wait_stream(side)
         else:
             for op in prog.ops:
                 if op.branch != 0:
-                    run_op(op)
+                    run_dec(op)
         logits = [outs[h] for h in prog.heads]
         extras = []
         for name in want:

@@ -18,7 +18,7 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, net, opts, x, *params):
         logits, S, extras = net._exec.forward(x, train=opts["train"], dtype=net.compute_dtype, save=opts["save"],
                                               update_stats=opts["update_stats"], drop_masks=opts["drop_masks"], rng=net._rng,
-                                              want=opts.get("want", ()))
+                                              want=opts.get("want", ()), perturb=opts.get("perturb"))
         ctx.net, ctx.S, ctx.nlogits = net, S, len(logits)
         ctx.grad_buffer = opts.get("grad_buffer")
         ctx.mark_non_differentiable(*extras)
@@ -167,7 +167,7 @@ class ChapNet(nn.Module):
         return r
 
     # ------------------------------------------------------------------ running the program
-    def _run(self, x, *, drop_masks=None, update_stats=True, want=(), grad_buffer=None):
+    def _run(self, x, *, drop_masks=None, update_stats=True, want=(), grad_buffer=None, perturb=None):
         if x.dim() != self.dims + 2 or x.shape[1] != 1:
             raise ValueError("chap_amd: expected input [N, 1, %s], got %s" % (", ".join("*" * self.dims), tuple(x.shape)))
         self._ensure_flat()
@@ -178,7 +178,10 @@ class ChapNet(nn.Module):
         if self._frozen or not grad_on:
             params = [p.detach() for p in params]
         save = grad_on and (x.requires_grad or any(p.requires_grad for p in params))
-        opts = dict(train=self.training, save=save, update_stats=update_stats, drop_masks=drop_masks, want=tuple(want), grad_buffer=grad_buffer)
+        if perturb is not None and save:
+            raise NotImplementedError("chap_amd: the channel-dropout pass (dropout=True) is forward-only: call it under torch.no_grad()")
+        opts = dict(train=self.training, save=save, update_stats=update_stats, drop_masks=drop_masks, want=tuple(want), grad_buffer=grad_buffer,
+                    perturb=perturb)
         return _NetFn.apply(self, opts, x, *params)
 
 

@@ -7,12 +7,18 @@ hand-scheduled HIP program (chap_amd.engine), not torch.nn calls.
     UpBlock     unet.py:78-99     [Conv1x1 -> bilinear x2 (align_corners)] | ConvTranspose2d k2 s2 ; cat ; ConvBlock
     Encoder     unet.py:125-151   Decoder unet.py:153-190   DualDecoder unet.py:245-292   UNet unet.py:498-552
 """
+import random
+
+import torch
 import torch.nn as nn
 
+from .. import ops as hip_ops
 from ..engine import Op, Program
+from ..ops import Lazy
 from .base import ChapNet, holder
 
 FT = (16, 32, 64, 128, 256)
+ENC_FEATURES = ("e0", "e1", "e2", "e3", "e4")      # value names of the five encoder outputs in the Program
 DROP = (0.05, 0.1, 0.2, 0.3, 0.5)
 SLOPE = 0.01
 
@@ -106,14 +112,58 @@ class DualDecoder(ChapNet):
         self._finish_init(build_program(class_num, [("decoder1", True), ("decoder2", self.decoder_type == "same")]))
 
     def forward(self, x, with_feat=False, dropout=False, dropout_level=None, scores=None, comp_dropout=False,
-                drop_masks=None, update_stats=True, grad_buffer=None):
-        if dropout:
-            raise NotImplementedError("chap_amd: channel-dropout branch (perform_dropout) is a next-row item, see DESIGN.md")
+                drop_masks=None, update_stats=True, grad_buffer=None, drop_uniforms=None, drop_branches=None):
+        perturb = None
+        if dropout:         # unet.py:280-284: both decoders on torch.cat((feat, perturbed unlabeled half)), B + U samples
+            perturb = self._channel_perturbation(x.shape[0], dropout_level, scores, comp_dropout, drop_uniforms, drop_branches)
         if with_feat:       # unet.py:289-290: also the five encoder features (materialised NCHW fp32, detached)
-            out = self._run(x, drop_masks=drop_masks, update_stats=update_stats, want=["e0", "e1", "e2", "e3", "e4"], grad_buffer=grad_buffer)
+            out = self._run(x, drop_masks=drop_masks, update_stats=update_stats, want=list(ENC_FEATURES), grad_buffer=grad_buffer,
+                            perturb=perturb)
             return out[0], out[1], list(out[2:])
-        out = self._run(x, drop_masks=drop_masks, update_stats=update_stats, grad_buffer=grad_buffer)
+        out = self._run(x, drop_masks=drop_masks, update_stats=update_stats, grad_buffer=grad_buffer, perturb=perturb)
         return out[0], out[1]
+
+    def _channel_perturbation(self, B, level, scores, comp, uniforms, branches):
+        """FilterDropout.perform_dropout (FilterDropout.py:45-89) on the lazy encoder features: the decoders' batch is
+        torch.cat((feat, feat[B//2:])) and the two channel masks become that batch's chan_mul rows (chap_channel_drop),
+        so the masked copies are never materialised.  drop_uniforms[idx] = (u1, u2) fp32 [U, C] and drop_branches[idx]
+        replace the device RNG / random.randint draws (tests)."""
+        if B % 2:
+            raise ValueError("chap_amd: dropout=True needs an even batch (labeled_bs = bs // 2 masks, FilterDropout.py:55-60)")
+        level = () if level is None else tuple(level)
+        U = B - B // 2
+
+        def perturb(vals, vdims):
+            ov1, ov2 = {}, {}
+            for idx, name in enumerate(ENC_FEATURES):
+                lz = vals[name]
+                assert lz.keep is None and lz.chan_mul is None
+                raw, Cc = lz.raw, lz.C
+                dev = raw.device
+                big = torch.empty((B + U,) + tuple(raw.shape[1:]), dtype=raw.dtype, device=dev)
+                big[:B].copy_(raw)
+                big[B:].copy_(raw[B // 2:])
+                mul1 = mul2 = None
+                if idx in level:
+                    if uniforms is not None:
+                        u1, u2 = (u.to(dev, torch.float32).contiguous() for u in uniforms[idx])
+                    else:
+                        u1, u2 = torch.empty(U, Cc, device=dev), torch.empty(U, Cc, device=dev)
+                        hip_ops.rand_uniform(u1, self._rng.next_seed(), seed_dev=self._rng.seed_dev)
+                        hip_ops.rand_uniform(u2, self._rng.next_seed(), seed_dev=self._rng.seed_dev)
+                    mul1, mul2 = torch.empty(B + U, Cc, device=dev), torch.empty(B + U, Cc, device=dev)
+                    if scores is None:
+                        hip_ops.channel_drop(mul1, mul2, u1, u2, B, "comp_binomial" if comp else "dropout2d")
+                    else:
+                        d_, h_, w_ = vdims[name]
+                        pooled = hip_ops.sample_channel_sum(Lazy(raw[B // 2:], lz.scale, lz.shift, lz.act, lz.slope))
+                        branch = (branches[idx] if branches is not None else random.randint(0, 1)) if comp else 0
+                        hip_ops.channel_drop(mul1, mul2, u1, u2, B, "scores", pool_partial=pooled, npix=d_ * h_ * w_,
+                                         grad_sim=scores[idx].to(dev, torch.float32).contiguous(), comp=comp, branch=branch)
+                ov1[name] = Lazy(big, lz.scale, lz.shift, lz.act, lz.slope, chan_mul=mul1)
+                ov2[name] = Lazy(big, lz.scale, lz.shift, lz.act, lz.slope, chan_mul=mul2)
+            return {1: ov1, 2: ov2}, B + U
+        return perturb
 
 
 class UNet(ChapNet):

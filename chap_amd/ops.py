@@ -314,6 +314,35 @@ def chan_mask(mul, seed, prob, seed_dev=None):
     L.call("chap_chan_mask", p, _stream())
 
 
+DROP_MODES = {"dropout2d": 0, "comp_binomial": 1, "scores": 2}
+
+
+def sample_channel_sum(lazy, nchunk=32):
+    """Per-sample spatial sums of a lazy activation [N, ..., C] as partial sums fp32 [N, nchunk, C] (fixed order)."""
+    p = L.SampleChanSumParams()
+    lazy.fill(p.r)
+    N = lazy.raw.shape[0]
+    partial = torch.empty(N, nchunk, lazy.C, dtype=torch.float32, device=lazy.raw.device)
+    p.partial, p.N, p.nchunk, p.pix_per_sample, p.dtype = partial.data_ptr(), N, nchunk, lazy.raw[0, ..., 0].numel(), dt(lazy.raw)
+    L.call("chap_sample_channel_sum", p, _stream())
+    return partial
+
+
+def channel_drop(mul1, mul2, u1, u2, B, mode, *, pool_partial=None, npix=1, grad_sim=None, comp=False, branch=0,
+                 prob_kind="sigmoid", probs_out=None):
+    """FilterDropout.perform_dropout's two channel masks of one level, as the chan_mul rows of the (B + U) decoder
+    batch: mul1/mul2 fp32 [B + U, C]; u1/u2 fp32 [U, C] uniforms."""
+    p = L.ChannelDropParams()
+    U, Cc = u1.shape
+    assert tuple(mul1.shape) == (B + U, Cc) and tuple(mul2.shape) == (B + U, Cc) and tuple(u2.shape) == (U, Cc)
+    p.pool_partial, p.grad_sim, p.u1, p.u2 = _p(pool_partial), _p(grad_sim), u1.data_ptr(), u2.data_ptr()
+    p.mul1, p.mul2, p.probs_out = mul1.data_ptr(), mul2.data_ptr(), _p(probs_out)
+    p.inv_npix, p.nchunk = 1.0 / npix, (pool_partial.shape[1] if pool_partial is not None else 0)
+    p.B, p.U, p.C, p.mode, p.comp, p.branch = B, U, Cc, DROP_MODES[mode], int(bool(comp)), int(branch)
+    p.prob_kind = {"sigmoid": 0, "gauss": 1}[prob_kind]
+    L.call("chap_channel_drop", p, _stream())
+
+
 def box_mix(a, b, out, box):
     """out = inside box ? b : a ; a/b/out [N, (1,) H, W] float32 or int64; box: device int32[4]."""
     p = L.BoxMixParams()

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define CHAP_ABI_VERSION 2
+#define CHAP_ABI_VERSION 3
 #define CHAP_ACT_BWD_REPS 32   /* replicas of the BN-backward partial sums (spreads float atomics) */
 
 enum { CHAP_F32 = 0, CHAP_BF16 = 1 };
@@ -342,6 +342,35 @@ typedef struct { const float* logits; const int32_t* origins; float* score; floa
 int chap_window_accumulate(const chap_window_acc_params* p, void* stream);
 typedef struct { float* score; const float* cnt; uint8_t* label; int32_t C; int64_t P; } chap_window_fin_params;
 int chap_window_finalize(const chap_window_fin_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Channel-level perturbation: FilterDropout.perform_dropout (FilterDropout.py:45-89) as two kernels.
+ *
+ * chap_sample_channel_sum: partial[n][k][c] = sum over the k-th pixel stripe of sample n of the lazy activation
+ * (adaptive_avg_pool2d(unlab_feat, 1), :75); fixed-order partial sums, no atomics.  r.ptr = the first pooled sample.
+ *
+ * chap_channel_drop: the two multipliers of one encoder level for the decoder batch torch.cat((feat, perturb_feat))
+ * (:86-87): rows [0, B) of mul1/mul2 are 1, rows [B, B+U) are the masks of the U unlabeled samples.
+ *   mode 0  two independent nn.Dropout2d(0.5) (:67-69):           m = u < 0.5 ? 2 : 0
+ *   mode 1  complementary Binomial(0.5) * 2 (:58-63):             m1 = u1 < 0.5 ? 2 : 0, m2 = 2 - m1
+ *   mode 2  scores_dropoutV2 (:116-138) + drop_based_on_prob (:140-160): s = grad_sim[c] * mean activation,
+ *           z over the channels of each sample (unbiased std), p_drop = sigmoid(-2 z) (prob_kind 0) or the 'gauss'
+ *           CDF with sigma * 2 (prob_kind 1); m = bernoulli(1 - p_drop), the complementary pair when comp
+ *           (branch = the reference's random.randint(0, 1)); m * numel / sum(m).  An all-zero grad_sim falls back
+ *           to mode 0 (:71-73) on the device.
+ * bernoulli(q) is (u < q) on the caller's uniforms u1, u2 [U][C] (chap_rand_uniform, or the test's).            */
+typedef struct { chap_src_t r; float* partial /* [N][nchunk][C] */; int32_t N, nchunk; int64_t pix_per_sample; int32_t dtype; } chap_sample_chansum_params;
+int chap_sample_channel_sum(const chap_sample_chansum_params* p, void* stream);
+typedef struct {
+    const float* pool_partial;  /* [U][nchunk][C] from chap_sample_channel_sum, or NULL (modes 0, 1)  */
+    const float* grad_sim;      /* [C] or NULL (modes 0, 1)                                           */
+    const float* u1; const float* u2;   /* [U][C] uniforms in [0, 1)                                   */
+    float* mul1; float* mul2;   /* [B + U][C]                                                         */
+    float* probs_out;           /* optional [U][C]: p_drop of mode 2                                  */
+    float inv_npix;             /* 1 / pixels per sample                                              */
+    int32_t nchunk, B, U, C, mode, comp, branch, prob_kind;
+} chap_channel_drop_params;
+int chap_channel_drop(const chap_channel_drop_params* p, void* stream);
 
 /* Bandwidth calibration helper (tools/membw.py): grid-stride float4 copy with `blocks` blocks of 256. */
 int chap_debug_copy(const void* src, void* dst, int64_t bytes, int32_t blocks, void* stream);

@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 sys.dont_write_bytecode = True
 
 from oracle import init as oinit  # noqa: E402
+from oracle import filter_dropout as ofd  # noqa: E402
 
 
 def _stub(name, **attrs):
@@ -250,12 +251,104 @@ def gen_3d(ref):
                         checks=_checks(list(md.state_dict().items())))
 
 
+class ScriptedDraws:
+    """While active, every random draw FilterDropout.py makes comes from a scripted list of uniform tensors:
+    torch.bernoulli(q) -> (u < q), Binomial(0.5).sample(shape) -> (u < 0.5), nn.Dropout2d(0.5)(x) -> x * 2 * (u < 0.5),
+    random.randint(0, 1) -> the scripted branch.  Patches torch / random attributes only (restored on exit); the
+    reference module itself is untouched."""
+
+    def __init__(self, uniforms, branches):
+        self.q = [u for pair in uniforms for u in pair]      # consumption order: level by level, mask 1 then mask 2
+        self.branches = list(branches)
+        self.pos = 0
+
+    def _next(self, shape):
+        u = self.q[self.pos]
+        self.pos += 1
+        assert tuple(u.shape) == tuple(shape), (u.shape, shape)
+        return u
+
+    def skip(self):
+        self.pos += 1
+
+    def __enter__(self):
+        import random
+        import torch.distributions.binomial as tdb
+        draws = self
+
+        class Drop2d(nn.Module):
+            def __init__(self, p):
+                super().__init__()
+                assert p == 0.5
+
+            def forward(self, x):
+                return x * ((draws._next(x.shape[:2]) < 0.5).to(x.dtype) * 2.0)[..., None, None]
+
+        self.saved = (torch.bernoulli, tdb.Binomial.sample, nn.Dropout2d, random.randint)
+        torch.bernoulli = lambda q: (draws._next(q.shape) < q).to(q.dtype)
+
+        def sample(self_, shape=torch.Size()):
+            m = (draws._next(tuple(shape)) < 0.5).float()
+            draws.skip()                                      # the complementary mask uses no second draw
+            return m
+        tdb.Binomial.sample = sample
+        nn.Dropout2d = Drop2d
+        random.randint = lambda a, b: draws.branches.pop(0)
+        return self
+
+    def __exit__(self, *a):
+        import random
+        import torch.distributions.binomial as tdb
+        torch.bernoulli, tdb.Binomial.sample, nn.Dropout2d, random.randint = self.saved
+
+
+FD_CASES = (  # name, scores given, comp, branch
+    ("drop2d", False, False, 0), ("binom", False, True, 0), ("scores", True, False, 0),
+    ("scores_comp0", True, True, 0), ("scores_comp1", True, True, 1))
+
+
+def gen_filter_dropout(ref):
+    """perform_dropout / scores_dropoutV2 / drop_based_on_prob of the imported reference under scripted draws, and
+    DualDecoder.forward(dropout=True) on top of it."""
+    feats, scores, uniforms = ofd.fd_inputs()
+    level = [0, 1, 2, 4]                                            # level 3 stays unperturbed
+    out = {"level": np.array(level)}
+    B = feats[0].shape[0]
+    for name, with_scores, comp, branch in FD_CASES:
+        with ScriptedDraws([uniforms[i] for i in level], [branch] * 5):
+            f1, f2 = ref["perform_dropout"]([f.clone() for f in feats], level, scores if with_scores else None, comp)
+        for idx, (a, b, f) in enumerate(zip(f1, f2, feats)):
+            unlab = f[B // 2:]
+            for tag, t in (("m1", a), ("m2", b)):
+                assert torch.equal(t[:B], f)
+                m = t[B:, :, 0, 0] / unlab[:, :, 0, 0]
+                assert torch.allclose(t[B:], m[..., None, None] * unlab, rtol=1e-6, atol=0)
+                out["%s_L%d_%s" % (name, idx, tag)] = _np(m)
+    # the whole dropout=True forward (train mode, injected encoder dropout), N = 4 -> 6 output samples
+    torch.manual_seed(0)
+    N, H, W = 4, 32, 32
+    m = ref["DualDecoder"](1, 4, {"decoder_type": "mcnet"})
+    m.load_state_dict(oinit.dual_decoder_2d_state(101), strict=True)
+    masks = oinit.drop_masks_2d(23, N, H, W)
+    blocks = [m.encoder.in_conv] + [getattr(m.encoder, "down%d" % i).maxpool_conv[1] for i in range(1, 5)]
+    for (site, keep), blk, p in zip(masks.items(), blocks, (0.05, 0.1, 0.2, 0.3, 0.5)):
+        blk.conv_conv[3] = Injected(keep, p)
+    x = torch.rand(N, 1, H, W, generator=torch.Generator().manual_seed(9))
+    m.train()
+    lv = [0, 1, 2, 3, 4]
+    with torch.no_grad(), ScriptedDraws(uniforms, [1] * 5):
+        o1, o2 = m(x, False, True, lv, scores, True)
+    out.update(fwd_x=_np(x), fwd_state_seed=101, fwd_mask_seed=23, fwd_logits1=_np(o1), fwd_logits2=_np(o2))
+    np.savez_compressed(os.path.join(OUT, "filter_dropout.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = import_reference()
     gen_2d(ref)
     gen_3d(ref)
+    gen_filter_dropout(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
