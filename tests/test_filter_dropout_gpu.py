@@ -100,3 +100,30 @@ def test_dropout_forward_is_forward_only_and_needs_even_batch():
     with torch.no_grad():                       # device RNG path: B + U outputs, finite
         o1, o2 = m(x, False, True, [0, 1, 2, 3, 4], None, True)
     assert o1.shape[0] == 3 and bool(torch.isfinite(o1).all()) and bool(torch.isfinite(o2).all())
+
+
+def test_gauss_probabilities_and_with_feat():
+    """scores_dropoutV2(type='gauss') (FilterDropout.py:126-130) and dropout=True together with with_feat=True."""
+    from chap_amd import ops
+    from chap_amd.networks import DualDecoder
+    feats, scores, uniforms = ofd.fd_inputs()
+    f, B = feats[1], feats[1].shape[0]
+    U, Cc = B // 2, f.shape[1]
+    mul1, mul2 = torch.empty(B + U, Cc, device=DEV), torch.empty(B + U, Cc, device=DEV)
+    probs = torch.empty(U, Cc, device=DEV)
+    pooled = ops.sample_channel_sum(ops.Lazy(_cl(f[U:]).to(DEV)), nchunk=3)
+    ops.channel_drop(mul1, mul2, uniforms[1][0].to(DEV), uniforms[1][1].to(DEV), B, "scores", pool_partial=pooled,
+                     npix=f.shape[2] * f.shape[3], grad_sim=scores[1].to(DEV), prob_kind="gauss", probs_out=probs)
+    want = ofd.drop_probs(scores[1], f[U:].mean(dim=(2, 3)), "gauss")
+    assert float((probs.cpu() - want).abs().max()) < 2e-5
+    m1, m2 = ofd.drop_based_on_prob(want, False, uniforms[1][0], uniforms[1][1])
+    assert torch.allclose(mul1[B:].cpu(), m1[..., 0, 0], rtol=1e-5) and torch.allclose(mul2[B:].cpu(), m2[..., 0, 0], rtol=1e-5)
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).eval()
+    x = torch.rand(2, 1, 32, 32, device=DEV)
+    with torch.no_grad():
+        o1, o2, fe = m(x, True, True, [4], None, False)
+        p1, p2, fe0 = m(x, True)
+    assert o1.shape[0] == 3 and len(fe) == 5 and fe[0].shape == (2, 16, 32, 32)
+    assert torch.equal(fe[0], fe0[0])
+    # eval mode: the first B samples of the perturbed pass see the same features and the same (running) BN statistics
+    assert float((o1[:2] - p1).abs().max()) < 1e-5 and float((o2[:2] - p2).abs().max()) < 1e-5
