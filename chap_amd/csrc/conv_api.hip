@@ -57,7 +57,7 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     else if (p->ksize == 1 && p->stride == 1) geom = 3;
     else if (p->ksize == 2 && p->stride == 2) geom = d3 ? 5 : 4;
     else { chap_set_error("chap_conv_fwd: unsupported (ksize=%d, stride=%d)", p->ksize, p->stride); return CHAP_EUNSUPPORTED; }
-    if (p->combine == 1 && p->nsrc == 2 && geom != 2) { chap_set_error("chap_conv_fwd: add-combine is built for 3D k3 s1 only"); return CHAP_EUNSUPPORTED; }
+    if (p->combine == 1 && p->nsrc == 2 && geom != 2 && geom != 1) { chap_set_error("chap_conv_fwd: add-combine is built for k3 s1 only"); return CHAP_EUNSUPPORTED; }
     // blocking: NT = 16-channel tiles per block, MR = 16-pixel rows per wave.  Large tiles (halo overhead,
     // weight reuse) when the layer has plenty of pixels; small tiles when it would not fill 256 CUs.
     int NT = b.ntiles >= 4 ? 4 : (b.ntiles >= 2 ? 2 : 1);

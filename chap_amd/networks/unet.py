@@ -36,7 +36,9 @@ def _encoder(in_chns):
     return enc
 
 
-def _decoder(n_class, bilinear):
+def _decoder(n_class, bilinear, plus=False):
+    """Decoder (unet.py:153-190: skip and up-sampled features concatenated) or, plus=True, Decoder_plus
+    (unet.py:192-243: UpBlock_plus adds them, so its ConvBlock takes c2 channels)."""
     dec = nn.Module()
     for k in range(1, 5):
         c1, c2 = FT[5 - k], FT[4 - k]
@@ -45,16 +47,16 @@ def _decoder(n_class, bilinear):
             up.add_module("conv1x1", nn.Conv2d(c1, c2, 1))
         else:
             up.add_module("up", nn.ConvTranspose2d(c1, c2, 2, stride=2))
-        up.add_module("conv", _conv_block(2 * c2, c2))
+        up.add_module("conv", _conv_block(c2 if plus else 2 * c2, c2))
         dec.add_module("up%d" % k, up)
     dec.add_module("out_conv", nn.Conv2d(FT[0], n_class, 3, padding=1))
     return dec
 
 
-def _block_ops(ops, pre, src, out, cin, cout, drop_p, first=False):
+def _block_ops(ops, pre, src, out, cin, cout, drop_p, first=False, combine=0):
     mid = out + ".a"
     kw = dict(w=pre + ".0.weight", b=pre + ".0.bias", bn=pre + ".1", slope=SLOPE, cin=cin, cout=cout,
-              drop=(pre, drop_p, "elem") if drop_p > 0 else None)
+              drop=(pre, drop_p, "elem") if drop_p > 0 else None, combine=combine)
     if first:
         ops.append(Op("c1", mid, [], **kw))
     else:
@@ -63,14 +65,15 @@ def _block_ops(ops, pre, src, out, cin, cout, drop_p, first=False):
 
 
 def build_program(n_class, decoders, enc_root="encoder"):
-    """decoders: list of (root name, bilinear?)."""
+    """decoders: list of (root name, bilinear?[, plus?])."""
     ops = []
     _block_ops(ops, enc_root + ".in_conv.conv_conv", None, "e0", 1, FT[0], DROP[0], first=True)
     for i in range(1, 5):
         ops.append(Op("pool", "p%d" % i, ["e%d" % (i - 1)]))
         _block_ops(ops, "%s.down%d.maxpool_conv.1.conv_conv" % (enc_root, i), ["p%d" % i], "e%d" % i, FT[i - 1], FT[i], DROP[i])
     heads = []
-    for bi, (root, bilinear) in enumerate(decoders):
+    for bi, (root, bilinear, *rest) in enumerate(decoders):
+        plus = bool(rest and rest[0])
         first_dec_op = len(ops)
         x = "e4"
         for k in range(1, 5):
@@ -83,7 +86,10 @@ def build_program(n_class, decoders, enc_root="encoder"):
             else:
                 ops.append(Op("deconv", u, [x], w=up + ".up.weight", b=up + ".up.bias", cin=c1, cout=c2))
             d = "%s.d%d" % (root, k)
-            _block_ops(ops, up + ".conv.conv_conv", ["e%d" % (4 - k), u], d, 2 * c2, c2, 0.0)
+            if plus:    # UpBlock_plus (unet.py:117-122): x = x2 + x1, summed while the conv loads its two sources
+                _block_ops(ops, up + ".conv.conv_conv", ["e%d" % (4 - k), u], d, c2, c2, 0.0, combine=1)
+            else:
+                _block_ops(ops, up + ".conv.conv_conv", ["e%d" % (4 - k), u], d, 2 * c2, c2, 0.0)
             x = d
         ops.append(Op("conv", root + ".logits", [x], ksize=3, w=root + ".out_conv.weight", b=root + ".out_conv.bias",
                       cin=FT[0], cout=n_class, head=True))
@@ -104,12 +110,13 @@ class DualDecoder(ChapNet):
         if in_chns != 1:
             raise NotImplementedError("chap_amd: in_chns=%d (the CHAP hot path is single-channel)" % in_chns)
         self.decoder_type = args["decoder_type"]
-        if self.decoder_type not in ("mcnet", "same"):
-            raise NotImplementedError("chap_amd: decoder_type=%r (mcnet/same built)" % self.decoder_type)
+        if self.decoder_type not in ("mcnet", "same", "plus"):
+            raise ValueError("chap_amd: decoder_type=%r (same | plus | mcnet, unet.py:270-275)" % self.decoder_type)
         self.encoder = _encoder(in_chns)
         self.decoder1 = _decoder(class_num, True)
-        self.decoder2 = _decoder(class_num, self.decoder_type == "same")
-        self._finish_init(build_program(class_num, [("decoder1", True), ("decoder2", self.decoder_type == "same")]))
+        bil2, plus2 = self.decoder_type in ("same", "plus"), self.decoder_type == "plus"      # unet.py:270-275
+        self.decoder2 = _decoder(class_num, bil2, plus2)
+        self._finish_init(build_program(class_num, [("decoder1", True), ("decoder2", bil2, plus2)]))
 
     def forward(self, x, with_feat=False, dropout=False, dropout_level=None, scores=None, comp_dropout=False,
                 drop_masks=None, update_stats=True, grad_buffer=None, drop_uniforms=None, drop_branches=None):

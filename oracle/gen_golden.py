@@ -181,6 +181,32 @@ def gen_2d(ref):
                         checks=_checks(list(md.state_dict().items())))
 
 
+def gen_2d_variants(ref):
+    """decoder_type 'plus' and 'same' (unet.py:270-275): eval and train-mode logits, input and picked weight gradients."""
+    N, H, W = 2, 32, 32
+    x = torch.rand(N, 1, H, W, generator=torch.Generator().manual_seed(17))
+    out = {"x": _np(x), "cot_seed": 13, "mask_seed": 25}
+    pick = ["decoder2.up3.conv1x1.weight", "decoder2.up4.conv.conv_conv.0.weight", "decoder2.up3.conv.conv_conv.0.weight",
+            "decoder2.up4.conv.conv_conv.5.weight", "encoder.down1.maxpool_conv.1.conv_conv.4.weight", "encoder.in_conv.conv_conv.0.weight"]
+    out["grad_pick_names"] = np.array(pick)
+    for dt, seed in (("plus", 111), ("same", 112)):
+        m = ref["DualDecoder"](1, 4, {"decoder_type": dt})
+        m.load_state_dict(oinit.dual_decoder_2d_state(seed, decoder_type=dt), strict=True)      # pins names + shapes
+        out[dt + "_state_seed"] = seed
+        r, params = run_case(m, x, 13, train=False)
+        out.update({"%s_eval_%s" % (dt, k): v for k, v in r.items()})
+        masks = oinit.drop_masks_2d(25, N, H, W)
+        blocks = [m.encoder.in_conv] + [getattr(m.encoder, "down%d" % i).maxpool_conv[1] for i in range(1, 5)]
+        for (site, keep), blk, p in zip(masks.items(), blocks, (0.05, 0.1, 0.2, 0.3, 0.5)):
+            blk.conv_conv[3] = Injected(keep, p)
+        r, params = run_case(m, x, 13, train=True, dtype=torch.float64)
+        out.update({"%s_train64_%s" % (dt, k): v for k, v in r.items()})
+        pd = dict(params)
+        for i, n in enumerate(pick):
+            out["%s_train64_grad_pick%d" % (dt, i)] = _np(pd[n].grad)
+    np.savez_compressed(os.path.join(OUT, "dualdecoder2d_variants_32.npz"), **out)
+
+
 def gen_3d(ref):
     N, D, H, W = 1, 32, 32, 16
     sd = oinit.dual_decoder_3d_state(201)
@@ -347,6 +373,7 @@ def main():
     torch.set_num_threads(8)
     ref = import_reference()
     gen_2d(ref)
+    gen_2d_variants(ref)
     gen_3d(ref)
     gen_filter_dropout(ref)
     for f in sorted(os.listdir(OUT)):

@@ -44,7 +44,7 @@ def _encoder2d(g, in_chns):
         _block2d(g, "encoder.down%d.maxpool_conv.1.conv_conv" % i, FT_2D[i - 1], FT_2D[i])
 
 
-def _decoder2d(g, root, n_class, bilinear):
+def _decoder2d(g, root, n_class, bilinear, plus=False):
     for k in range(1, 5):
         c1, c2 = FT_2D[5 - k], FT_2D[4 - k]
         up = "%s.up%d" % (root, k)
@@ -52,16 +52,17 @@ def _decoder2d(g, root, n_class, bilinear):
             g.conv(up + ".conv1x1", (c2, c1, 1, 1), c1, c2)
         else:
             g.conv(up + ".up", (c1, c2, 2, 2), c1, c2)
-        _block2d(g, up + ".conv.conv_conv", 2 * c2, c2)
+        _block2d(g, up + ".conv.conv_conv", c2 if plus else 2 * c2, c2)
     g.conv(root + ".out_conv", (n_class, FT_2D[0], 3, 3), FT_2D[0] * 9, n_class)
 
 
-def dual_decoder_2d_state(seed, in_chns=1, n_class=4):
-    """202 tensors; decoder1 bilinear, decoder2 transposed-conv ('mcnet')."""
+def dual_decoder_2d_state(seed, in_chns=1, n_class=4, decoder_type="mcnet"):
+    """202 tensors; decoder1 bilinear, decoder2 transposed-conv ('mcnet'), bilinear ('same') or bilinear with
+    additive skips ('plus')  -- unet.py:270-275."""
     g = _Gen(seed)
     _encoder2d(g, in_chns)
     _decoder2d(g, "decoder1", n_class, True)
-    _decoder2d(g, "decoder2", n_class, False)
+    _decoder2d(g, "decoder2", n_class, decoder_type != "mcnet", decoder_type == "plus")
     return g.sd
 
 

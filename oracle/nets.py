@@ -12,6 +12,7 @@ Reference definitions followed (paths relative to /root/reference):
       UpBlock        code/networks/unet.py:78-99
       Encoder        code/networks/unet.py:125-151
       Decoder        code/networks/unet.py:153-190
+      UpBlock_plus / Decoder_plus   code/networks/unet.py:100-122, 192-243
       DualDecoder    code/networks/unet.py:245-292
       UNet           code/networks/unet.py:498-552
   3D  ConvBlock      code/networks/vnet.py:8-34
@@ -104,7 +105,10 @@ def decoder_2d(sd, root, feats, ctx):
             x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
         else:
             x = F.conv_transpose2d(x, sd[up + ".up.weight"], sd[up + ".up.bias"], stride=2)
-        x = conv_block_2d(sd, up + ".conv.conv_conv", torch.cat([skip, x], 1), 0.0, ctx)
+        if sd[up + ".conv.conv_conv.0.weight"].shape[1] == skip.shape[1]:      # UpBlock_plus (unet.py:100-122): x2 + x1
+            x = conv_block_2d(sd, up + ".conv.conv_conv", skip + x, 0.0, ctx)
+        else:
+            x = conv_block_2d(sd, up + ".conv.conv_conv", torch.cat([skip, x], 1), 0.0, ctx)
     return F.conv2d(x, sd[root + ".out_conv.weight"], sd[root + ".out_conv.bias"], padding=1)
 
 

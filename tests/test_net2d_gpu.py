@@ -165,3 +165,38 @@ def test_with_feat_returns_encoder_features(golden_dir):
     assert relerr(o1, r1) < 1e-4 and len(feats) == 5
     for a, b in zip(feats, rf):
         assert a.shape == b.shape and relerr(a, b) < 1e-4
+
+
+@pytest.mark.parametrize("decoder_type", ["plus", "same"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_dualdecoder_plus_and_same(golden_dir, decoder_type, dtype):
+    """decoder_type 'plus' (UpBlock_plus: skip + up-sampled, summed while the conv loads its two sources) and 'same'
+    (unet.py:270-275): eval logits and gradients, train-mode logits and gradients against the reference's fp64 run."""
+    g = _load(golden_dir, "dualdecoder2d_variants_32.npz")
+    dt = decoder_type
+    m = DualDecoder(1, 4, {"decoder_type": dt}).to(DEV)
+    m.load_state_dict(oinit.dual_decoder_2d_state(int(g[dt + "_state_seed"]), decoder_type=dt), strict=True)
+    m.set_compute_dtype(dtype).eval()
+    x = g["x"]
+    outs, dx = run_case(m, x, int(g["cot_seed"]))
+    tol = 1e-4 if dtype == torch.float32 else 4e-2
+    assert relerr(outs[0], g[dt + "_eval_logits0"]) < tol and relerr(outs[1], g[dt + "_eval_logits1"]) < tol
+    if dtype == torch.float32:
+        assert relerr(dx, g[dt + "_eval_dx"]) < 2e-3
+        got = np.array([float(p.grad.double().abs().sum()) for _, p in m.named_parameters()])
+        np.testing.assert_allclose(got, g[dt + "_eval_grad_checks"][:, 1], rtol=5e-3, atol=1e-4)
+    else:
+        assert cosine(dx, g[dt + "_eval_dx"]) > 0.9
+    m.train()
+    masks = oinit.drop_masks_2d(int(g["mask_seed"]), x.shape[0], x.shape[2], x.shape[3])
+    outs, dx = run_case(m, x, int(g["cot_seed"]), drop_masks=cl_masks(masks))
+    assert relerr(outs[0], g[dt + "_train64_logits0"]) < (1e-4 if dtype == torch.float32 else 1.5e-1)
+    assert relerr(outs[1], g[dt + "_train64_logits1"]) < (1e-4 if dtype == torch.float32 else 1.5e-1)
+    if dtype == torch.float32:
+        grads = dict(m.named_parameters())
+        # train-mode BN over 8 values per channel at the bottleneck: fp32 gradients (the reference's own too, see
+        # test_dualdecoder_train_injected) sit ~1e-2 from the fp64 run; direction to 1e-3, size to 1e-1
+        assert relerr(dx, g[dt + "_train64_dx"]) < 1e-1 and cosine(dx, g[dt + "_train64_dx"]) > 0.999
+        for i, n in enumerate(g["grad_pick_names"]):
+            want = g["%s_train64_grad_pick%d" % (dt, i)]
+            assert relerr(grads[str(n)].grad, want) < 1e-1 and cosine(grads[str(n)].grad, want) > 0.999, n

@@ -154,3 +154,22 @@ def test_vnet_and_unet3d(golden_dir):
     with torch.no_grad():
         o = nets.unet_3d(state, torch.from_numpy(g["x"]))
     assert _relerr(o, g["eval_logits0"]) < 1e-5
+
+
+def test_dualdecoder2d_plus_and_same_variants(golden_dir):
+    """decoder_type 'plus' (Decoder_plus, additive skips) and 'same' (unet.py:270-275) against the reference."""
+    g = _load(golden_dir, "dualdecoder2d_variants_32.npz")
+    x = g["x"]
+    masks = oinit.drop_masks_2d(int(g["mask_seed"]), x.shape[0], x.shape[2], x.shape[3])
+    for dt in ("plus", "same"):
+        state = oinit.dual_decoder_2d_state(int(g[dt + "_state_seed"]), decoder_type=dt)
+        sd = _sd(state)
+        outs, dx, _ = _run(nets.dual_decoder_2d, sd, x, int(g["cot_seed"]), train=False)
+        assert _relerr(outs[0], g[dt + "_eval_logits0"]) < 1e-5 and _relerr(outs[1], g[dt + "_eval_logits1"]) < 1e-5
+        assert _relerr(dx, g[dt + "_eval_dx"]) < 1e-4
+        sd64 = _sd(state, dtype=torch.float64)
+        outs, dx, _ = _run(nets.dual_decoder_2d, sd64, x, int(g["cot_seed"]), dtype=torch.float64, train=True, drop=masks)
+        assert _relerr(outs[1], g[dt + "_train64_logits1"]) < 1e-6
+        assert _relerr(dx, g[dt + "_train64_dx"]) < 1e-5
+        for i, n in enumerate(g["grad_pick_names"]):
+            assert _relerr(sd64[str(n)].grad, g["%s_train64_grad_pick%d" % (dt, i)]) < 1e-5, (dt, n)
