@@ -172,7 +172,9 @@ def test_ablation_iteration_matches_oracle():
         floor = 3e-7 * v.detach().abs().max().item()
         if upd > 0 and max(d - floor, 0.0) / upd > worst:
             worst, worst_key = max(d - floor, 0.0) / upd, k
-    assert worst < 0.05, (worst, worst_key)
+    # the BN statistics are float-atomic sums: their last-bit run-to-run noise goes through the normalisation of the (tiny)
+    # power-iteration gradient and comes out as 0.5 % .. 5 % of this one update (8 repetitions, tests/perf/ablation_tol_probe.py)
+    assert worst < 0.1, (worst, worst_key)
     assert step.iter_num == it0 + 1
     with pytest.raises(NotImplementedError):
         step.capture(vol.to(DEV), lab.to(DEV))
