@@ -23,7 +23,16 @@ for k, v in sd.items():
         v.requires_grad_(True)
 moms = {k: torch.zeros_like(v) for k, v in sd.items() if v.requires_grad}
 ots.ablation_iteration(sd, moms, vol, lab, iter_num=3000, lr=0.01, args=args, inject=inj_cpu)
+def poison():
+    """Fill the caching allocator's free blocks with NaN so that a read of uninitialised memory shows up."""
+    junk = [torch.full((1 << k,), float("nan"), device=DEV) for k in range(7, 26) for _ in range(3)]
+    torch.cuda.synchronize()
+    del junk
+
+
 for rep in range(8):
+    if os.environ.get("CHAP_POISON") == "1":
+        poison()
     m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train()
     m.load_state_dict(state, strict=True)
     step = AblationStep(m, args)
@@ -42,4 +51,15 @@ for rep in range(8):
         if upd > 0:
             res.append((max(d - floor, 0.0) / upd, k))
     res.sort(reverse=True)
+    num = den = 0.0
+    cos_min = 1.0
+    for k, v in sd.items():
+        if not v.is_floating_point() or k.endswith(("running_mean", "running_var")):
+            continue
+        ug = (after[k].cpu().double() - state[k].double()).flatten()
+        uo = (v.detach().double() - state[k].double()).flatten()
+        num += float(((ug - uo) ** 2).sum()); den += float((uo ** 2).sum())
+        if float(uo.norm()) > 0:
+            cos_min = min(cos_min, float((ug * uo).sum() / (ug.norm() * uo.norm() + 1e-300)))
+    print("   global rel-L2 of the update %.4f, min per-tensor cosine %.5f" % ((num / den) ** 0.5, cos_min), flush=True)
     print(rep, " ".join("%.4f:%s" % (e, k.replace("conv_conv.", "").replace("decoder", "d")) for e, k in res[:3]), flush=True)

@@ -172,9 +172,26 @@ def test_ablation_iteration_matches_oracle():
         floor = 3e-7 * v.detach().abs().max().item()
         if upd > 0 and max(d - floor, 0.0) / upd > worst:
             worst, worst_key = max(d - floor, 0.0) / upd, k
-    # the BN statistics are float-atomic sums: their last-bit run-to-run noise goes through the normalisation of the (tiny)
-    # power-iteration gradient and comes out as 0.5 % .. 5 % of this one update (8 repetitions, tests/perf/ablation_tol_probe.py)
-    assert worst < 0.1, (worst, worst_key)
+    # The BN statistics are float-atomic sums; their last-bit run-to-run noise flips a few discrete decisions of this small
+    # fixture (max-pool routing, arg-max targets, the top-k patch threshold), so single ELEMENTS of an update move by
+    # 3 % .. 20 % of the tensor's largest update from run to run, while the update as a whole is stable: over 8 repetitions
+    # (tests/perf/ablation_tol_probe.py) global relative L2 error 0.006 .. 0.008, smallest per-tensor cosine 0.9991.
+    assert worst < 0.5, (worst, worst_key)
+    num = den = 0.0
+    cos_min, cos_key = 1.0, None
+    for k, v in sd.items():
+        if not v.is_floating_point() or k.endswith(("running_mean", "running_var")):
+            continue
+        ug = (after[k].cpu().double() - state[k].double()).flatten()
+        uo = (v.detach().double() - state[k].double()).flatten()
+        num += float(((ug - uo) ** 2).sum())
+        den += float((uo ** 2).sum())
+        if float(uo.norm()) > 0:
+            c = float((ug * uo).sum() / (ug.norm() * uo.norm() + 1e-300))
+            if c < cos_min:
+                cos_min, cos_key = c, k
+    assert (num / den) ** 0.5 < 0.03, (num / den) ** 0.5
+    assert cos_min > 0.995, (cos_min, cos_key)
     assert step.iter_num == it0 + 1
     with pytest.raises(NotImplementedError):
         step.capture(vol.to(DEV), lab.to(DEV))
