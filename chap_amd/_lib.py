@@ -165,6 +165,11 @@ class ChannelDropParams(C.Structure):
                 ("mode", _i32), ("comp", _i32), ("branch", _i32), ("prob_kind", _i32)]
 
 
+class FoldParams(C.Structure):
+    _fields_ = [("g", _vp), ("mul", _vp), ("out", _vp), ("B", _i32), ("U", _i32), ("C", _i32), ("ld", _i32), ("coff", _i32),
+                ("pix_per_sample", _i64), ("dtype", _i32)]
+
+
 class BoxMixParams(C.Structure):
     _fields_ = [("a", _vp), ("b", _vp), ("out", _vp), ("box", _vp), ("N", _i32), ("H", _i32), ("W", _i32), ("is_i64", _i32), ("D", _i32)]
 
@@ -200,6 +205,7 @@ _SIGS = {  # name -> (restype, params struct or None)
     "chap_box_mix": BoxMixParams, "chap_box_mask": BoxMaskParams, "chap_largest_cc": LccParams,
     "chap_diff_mask": DiffMaskParams, "chap_sgd_step": SgdParams,
     "chap_sample_channel_sum": SampleChanSumParams, "chap_channel_drop": ChannelDropParams,
+    "chap_fold_perturbed": FoldParams,
 }
 _SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParams, "chap_wgrad_ws": WgradParams,
              "chap_lcc_ws": LccParams}

@@ -5,6 +5,7 @@
 //                             as fixed-order partial sums so that the masks do not depend on atomic ordering
 //   chap_channel_drop         the two per-(sample, channel) multipliers of one encoder level, written as the
 //                             chan_mul rows of the (B + U)-sample decoder batch  torch.cat((feat, perturb_feat))  (:86-87)
+//   chap_fold_perturbed       the adjoint of that cat: gradient of the (B + U)-sample batch -> gradient of the B samples
 #include "common.h"
 
 template <typename T>
@@ -140,5 +141,47 @@ extern "C" int chap_channel_drop(const chap_channel_drop_params* p, void* stream
     const size_t lds = (size_t)p->U * p->C * sizeof(float);
     hipLaunchKernelGGL(channel_drop_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_channel_drop");
+    return CHAP_OK;
+}
+
+// out[n] = g[n] (n < B);  out[B - U + u] += mul[B + u] * g[B + u]   -- channel slice [coff, coff + C) of g (row length ld)
+template <typename T>
+__global__ __launch_bounds__(256) void fold_perturbed_kernel(const chap_fold_params P) {
+    const int C8 = P.C / 8;
+    const long per_sample = P.pix_per_sample * C8;
+    const long total = (long)P.B * per_sample;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / per_sample);
+        const long r = i - (long)n * per_sample;
+        const long pp = r / C8;
+        const int c8 = (int)(r - pp * C8) * 8;
+        float v[8];
+        ld8((const T*)P.g + ((long)n * P.pix_per_sample + pp) * P.ld + P.coff + c8, v);
+        const int u = n - (P.B - P.U);
+        if (u >= 0) {
+            float w[8];
+            ld8((const T*)P.g + ((long)(P.B + u) * P.pix_per_sample + pp) * P.ld + P.coff + c8, w);
+            if (P.mul) {
+                float m[8];
+                ld8(P.mul + (long)(P.B + u) * P.C + c8, m);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaf(w[j], m[j], v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += w[j];
+            }
+        }
+        st8((T*)P.out + ((long)n * P.pix_per_sample + pp) * P.C + c8, v);
+    }
+}
+
+extern "C" int chap_fold_perturbed(const chap_fold_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->g && p->out && p->B > 0 && p->U >= 0 && p->U <= p->B && p->pix_per_sample > 0, "chap_fold_perturbed: bad argument");
+    CHAP_CHECK_ARG(p->C % 8 == 0 && p->ld % 8 == 0 && p->coff % 8 == 0 && p->coff + p->C <= p->ld, "chap_fold_perturbed: C=%d ld=%d coff=%d must be multiples of 8", p->C, p->ld, p->coff);
+    const long total = (long)p->B * p->pix_per_sample * (p->C / 8);
+    const int blocks = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
+    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(fold_perturbed_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL(fold_perturbed_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_fold_perturbed");
     return CHAP_OK;
 }

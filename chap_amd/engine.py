@@ -69,6 +69,9 @@ class Saved:
         self.x = None
         self.xpad = None     # bf16 mode: the input zero-padded to 16 channels (channel-last)
         self.train = False
+        self.tables = None   # perturbed pass: branch -> value table of that decoder (trunk values overlaid)
+        self.fold = {}       # perturbed pass: branch -> {trunk value name: chan_mul [B + U, C] or None}
+        self.n_dec = 0       # perturbed pass: the decoders' batch size B + U
 
 
 class Executor:
@@ -300,9 +303,11 @@ class Executor:
         if perturb is not None:
             # channel-level perturbation (FilterDropout.perform_dropout): every decoder gets its own version of the
             # trunk's values -- a larger batch with per-(sample, channel) multipliers -- and runs on that batch
-            assert not save, "the perturbed pass is forward-only"
             overlays, n_dec = perturb(vals, vdims)
             tables = {b: dict(vals, **overlays[b]) for b in branches if b != 0}
+            if save:
+                S.tables, S.n_dec = tables, n_dec
+                S.fold = {b: {name: lz.chan_mul for name, lz in overlays[b].items()} for b in tables}
             run_dec = lambda op: run_op(op, tables[op.branch], n_dec)      # noqa: E731
         else:
             run_dec = run_op
@@ -355,7 +360,22 @@ class Executor:
             spos[0] += n
             return t
 
+        def scatter(op, srcs, dsrc):
+            muls = S.fold.get(op.branch) if S.tables is not None else None
+            if not muls:
+                return self._scatter(contrib, op, srcs, dsrc)
+            off = 0
+            for name, s in zip(op.srcs, srcs):
+                o = off if op.combine == 0 else 0
+                if name in muls:        # a trunk value seen through cat((feat, mul * feat[B-U:])): fold the gradient back to B samples
+                    contrib.setdefault(name, []).append((ops.fold_perturbed(dsrc, o, s.C, muls[name], N, S.n_dec - N), 0))
+                else:
+                    contrib.setdefault(name, []).append((dsrc, o))
+                off += s.C
+
         def bwd_op(op):
+            # a perturbed pass (FilterDropout): the decoders ran on their own value tables and batch of B + U samples
+            V, n = (S.tables[op.branch], S.n_dec) if (S.tables is not None and op.branch != 0) else (S.vals, N)
             nonlocal dx
             k = op.kind
             if k == "pool":
@@ -368,9 +388,9 @@ class Executor:
                 c = contrib.get(op.out)
                 if c:
                     assert len(c) == 1
-                    src = S.vals[op.srcs[0]]
+                    src = V[op.srcs[0]]
                     d, h, w = S.dims[op.srcs[0]]
-                    o = torch.empty(N, d, h, w, src.C, dtype=dtype, device=dev)
+                    o = torch.empty(n, d, h, w, src.C, dtype=dtype, device=dev)
                     ops.upsample2x_bwd(c[0][0], c[0][1], src.C, o, dims=dims)
                     contrib.setdefault(op.srcs[0], []).append((o, 0))
                 return
@@ -380,7 +400,7 @@ class Executor:
                 if dl is None:
                     return
                 gd = S.dims[op.out]
-                g16 = torch.empty((N,) + gd + (16,), dtype=dtype, device=dev)
+                g16 = torch.empty((n,) + gd + (16,), dtype=dtype, device=dev)
                 ops.planar_to_cl(dl, g16, cpad=16)
                 g = Lazy(g16)
                 kn_valid = op.cout
@@ -389,14 +409,14 @@ class Executor:
                 pl = pooled.get(op.out)
                 if not c and pl is None:
                     return
-                v = S.vals[op.out]
+                v = V[op.out]
                 gd = S.dims[op.out]
                 kn_valid = 0
                 plain = (v.scale is None and not v.act and v.keep is None and v.chan_mul is None)
                 if plain and pl is None and len(c) == 1:
                     g = Lazy(c[0][0], C=v.C, coff=c[0][1])
                 else:
-                    gout = torch.empty((N,) + gd + (v.C,), dtype=dtype, device=dev)
+                    gout = torch.empty((n,) + gd + (v.C,), dtype=dtype, device=dev)
                     kw = {}
                     if op.bn:
                         if S.train:
@@ -421,56 +441,56 @@ class Executor:
                 gt = g.raw if (g.coff == 0 and g.C == g.ld) else None
                 assert gt is not None
                 if need_dx:
-                    dx = torch.empty_like(S.x)      # [N, 1, *spatial] fp32 == planar output with one channel
+                    dx = torch.empty_like(S.x)      # [n, 1, *spatial] fp32 == planar output with one channel
                     wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
-                    ops.conv_fwd([g], wp, None, 1, dx, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=dims,
+                    ops.conv_fwd([g], wp, None, 1, dx, grid=(n, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=dims,
                                  out_planar=True, out_f32=True)
                 if need_wgrad:
                     if S.xpad is not None:
                         taps = 3 ** dims
-                        ops.wgrad([Lazy(S.xpad)], g, gr[op.w], (1, taps, taps), grid=(N, D, H, W), in_dims=(D, H, W),
+                        ops.wgrad([Lazy(S.xpad)], g, gr[op.w], (1, taps, taps), grid=(n, D, H, W), in_dims=(D, H, W),
                                   ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=1)
                     else:
-                        ops.conv_c1_bwd(gt, sd[op.w], S.x.view(N, D, H, W), dims=dims, dx=None,
+                        ops.conv_c1_bwd(gt, sd[op.w], S.x.view(n, D, H, W), dims=dims, dx=None,
                                         dw=gr[op.w], db=gr[op.b] if op.b else None)
                 return
-            srcs = [S.vals[s] for s in op.srcs]
+            srcs = [V[s] for s in op.srcs]
             sd_, sh_, sw_ = S.dims[op.srcs[0]]
             ctot = sum(s.C for s in srcs) if op.combine == 0 else srcs[0].C
             if k == "conv":
                 taps = op.ksize ** dims
                 if need_wgrad:
-                    ops.wgrad(srcs, g, gr[op.w], (1, taps, ctot * taps), grid=(N, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
+                    ops.wgrad(srcs, g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
                               ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid)
                 if self._needs_src_grad(op, need_dx):
                     wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
-                    dsrc = torch.empty(N, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
-                    ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(N, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
-                    self._scatter(contrib, op, srcs, dsrc)
+                    dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                    ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
+                    scatter(op, srcs, dsrc)
             elif k == "down":
                 gdd = S.dims[op.out]
                 if need_wgrad:
-                    ops.wgrad(srcs, g, gr[op.w], (1, nsub, ctot * nsub), grid=(N,) + gdd, in_dims=(sd_, sh_, sw_),
+                    ops.wgrad(srcs, g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
                               ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None)
                 if self._needs_src_grad(op, need_dx):
                     wp = self._pack(op, L.PACK_DOWN_DGRAD, dtype, sd)
-                    dsrc = torch.empty(N, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
-                    ops.conv_fwd([g], wp, None, nsub * ctot, dsrc, grid=(N,) + gdd, in_dims=gdd, ksize=1, stride=1, dims=dims,
+                    dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                    ops.conv_fwd([g], wp, None, nsub * ctot, dsrc, grid=(n,) + gdd, in_dims=gdd, ksize=1, stride=1, dims=dims,
                                  out_mode=1, out_cn=ctot)
-                    self._scatter(contrib, op, srcs, dsrc)
+                    scatter(op, srcs, dsrc)
             else:  # deconv: A = fine gradient (kc = co), B = coarse input (kn = ci)
                 fine = S.dims[op.out]
                 if need_wgrad:
                     assert len(srcs) == 1
-                    ops.wgrad([g], srcs[0], gr[op.w], (1, nsub, op.cout * nsub), grid=(N, sd_, sh_, sw_), in_dims=fine,
+                    ops.wgrad([g], srcs[0], gr[op.w], (1, nsub, op.cout * nsub), grid=(n, sd_, sh_, sw_), in_dims=fine,
                               ksize=2, stride=2, dims=dims)
                     if op.b:
                         ops.channel_sum(g, gr[op.b])
                 if self._needs_src_grad(op, need_dx):
                     wp = self._pack(op, L.PACK_DECONV_DGRAD, dtype, sd)
-                    dsrc = torch.empty(N, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
-                    ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(N, sd_, sh_, sw_), in_dims=fine, ksize=2, stride=2, dims=dims)
-                    self._scatter(contrib, op, srcs, dsrc)
+                    dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                    ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=fine, ksize=2, stride=2, dims=dims)
+                    scatter(op, srcs, dsrc)
         # ---- schedule: the decoders' backward passes side by side, then the shared trunk
         cur_stream = torch.cuda.current_stream()
         rev = list(reversed(prog.ops))

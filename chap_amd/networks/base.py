@@ -178,8 +178,6 @@ class ChapNet(nn.Module):
         if self._frozen or not grad_on:
             params = [p.detach() for p in params]
         save = grad_on and (x.requires_grad or any(p.requires_grad for p in params))
-        if perturb is not None and save:
-            raise NotImplementedError("chap_amd: the channel-dropout pass (dropout=True) is forward-only: call it under torch.no_grad()")
         opts = dict(train=self.training, save=save, update_stats=update_stats, drop_masks=drop_masks, want=tuple(want), grad_buffer=grad_buffer,
                     perturb=perturb)
         return _NetFn.apply(self, opts, x, *params)

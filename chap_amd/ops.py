@@ -343,6 +343,17 @@ def channel_drop(mul1, mul2, u1, u2, B, mode, *, pool_partial=None, npix=1, grad
     L.call("chap_channel_drop", p, _stream())
 
 
+def fold_perturbed(g, coff, Cc, mul, B, U):
+    """Adjoint of cat((feat, mul * feat[B-U:])): g [B + U, ..., ld] (channels [coff, coff + Cc)) -> [B, ..., Cc]."""
+    p = L.FoldParams()
+    out = torch.empty((B,) + tuple(g.shape[1:-1]) + (Cc,), dtype=g.dtype, device=g.device)
+    p.g, p.mul, p.out = g.data_ptr(), _p(mul), out.data_ptr()
+    p.B, p.U, p.C, p.ld, p.coff = B, U, Cc, g.shape[-1], coff
+    p.pix_per_sample, p.dtype = g[0, ..., 0].numel(), dt(g)
+    L.call("chap_fold_perturbed", p, _stream())
+    return out
+
+
 def box_mix(a, b, out, box):
     """out = inside box ? b : a ; a/b/out [N, (1,) H, W] float32 or int64; box: device int32[4]."""
     p = L.BoxMixParams()

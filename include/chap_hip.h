@@ -371,6 +371,11 @@ typedef struct {
     int32_t nchunk, B, U, C, mode, comp, branch, prob_kind;
 } chap_channel_drop_params;
 int chap_channel_drop(const chap_channel_drop_params* p, void* stream);
+/* Adjoint of torch.cat((feat, mul * feat[B-U:])) for the backward pass of the perturbed decoders: g is the gradient
+ * w.r.t. the (B + U)-sample batch (channel-last, row length ld, channels [coff, coff + C)), out [B][pix][C] the gradient
+ * w.r.t. feat: out[n] = g[n], and for the unlabeled rows out[B-U+u] += mul[B+u][c] * g[B+u] (mul NULL: plain sum).     */
+typedef struct { const void* g; const float* mul; void* out; int32_t B, U, C, ld, coff; int64_t pix_per_sample; int32_t dtype; } chap_fold_params;
+int chap_fold_perturbed(const chap_fold_params* p, void* stream);
 
 /* Bandwidth calibration helper (tools/membw.py): grid-stride float4 copy with `blocks` blocks of 256. */
 int chap_debug_copy(const void* src, void* dst, int64_t bytes, int32_t blocks, void* stream);

@@ -75,7 +75,7 @@ def perform_dropout(feats, level, scores, comp, uniforms, branches=None):
                     m2 = (u2 < 0.5).float() * 2.0
                 m1, m2 = m1[..., None, None], m2[..., None, None]
             else:
-                act = unlab.mean(dim=(2, 3))                            # adaptive_avg_pool2d(unlab_feat, (1, 1))
+                act = unlab.detach().mean(dim=(2, 3))                            # adaptive_avg_pool2d(unlab_feat, (1, 1))
                 m1, m2 = scores_dropout_v2(scores[idx], act, comp, "sigmoid", u1, u2, 0 if branches is None else branches[idx])
             p1, p2 = m1 * unlab, m2 * unlab
         else:

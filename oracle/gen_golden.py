@@ -365,6 +365,32 @@ def gen_filter_dropout(ref):
     with torch.no_grad(), ScriptedDraws(uniforms, [1] * 5):
         o1, o2 = m(x, False, True, lv, scores, True)
     out.update(fwd_x=_np(x), fwd_state_seed=101, fwd_mask_seed=23, fwd_logits1=_np(o1), fwd_logits2=_np(o2))
+    # backward through the perturbed pass: eval mode (running statistics: well conditioned, fp32) and train mode in fp64
+    pick = ["decoder1.up3.conv1x1.weight", "decoder2.up3.up.weight", "decoder2.up4.conv.conv_conv.0.weight",
+            "decoder1.up3.conv.conv_conv.1.weight", "encoder.down4.maxpool_conv.1.conv_conv.5.bias",
+            "encoder.down1.maxpool_conv.1.conv_conv.4.weight", "encoder.in_conv.conv_conv.0.weight"]
+    out["bwd_pick_names"] = np.array(pick)
+    out["bwd_cot_seed"] = 31
+    for tag, train, dtype in (("eval", False, torch.float32), ("train64", True, torch.float64)):
+        mm = ref["DualDecoder"](1, 4, {"decoder_type": "mcnet"})
+        mm.load_state_dict(oinit.dual_decoder_2d_state(101), strict=True)
+        blocks = [mm.encoder.in_conv] + [getattr(mm.encoder, "down%d" % i).maxpool_conv[1] for i in range(1, 5)]
+        for (site, keep), blk, p in zip(masks.items(), blocks, (0.05, 0.1, 0.2, 0.3, 0.5)):
+            blk.conv_conv[3] = Injected(keep, p)
+        mm.train(train)
+        mm.to(dtype)
+        xx = x.clone().to(dtype).requires_grad_(True)
+        with ScriptedDraws(uniforms, [1] * 5):
+            o1, o2 = mm(xx, False, True, lv, scores, True)
+        g = torch.Generator().manual_seed(31)
+        loss = sum((o * torch.randn(o.shape, generator=g).to(dtype)).sum() for o in (o1, o2))
+        loss.backward()
+        pd = dict(mm.named_parameters())
+        out["bwd_%s_logits1" % tag] = _np(o1)
+        out["bwd_%s_dx" % tag] = _np(xx.grad)
+        out["bwd_%s_grad_checks" % tag] = _checks([(n, p.grad) for n, p in mm.named_parameters()])
+        for i, n in enumerate(pick):
+            out["bwd_%s_grad_pick%d" % (tag, i)] = _np(pd[n].grad)
     np.savez_compressed(os.path.join(OUT, "filter_dropout.npz"), **out)
 
 

@@ -52,3 +52,30 @@ def test_dropout_forward_matches_reference():
     for o, key in ((o1, "fwd_logits1"), (o2, "fwd_logits2")):
         want = torch.from_numpy(G[key])
         assert float((o - want).abs().max()) <= 1e-4 * max(1.0, float(want.abs().max()))
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def test_dropout_backward_matches_reference():
+    """Gradients through the perturbed pass (masks are constants, the pooled activation is detached, FilterDropout.py:76):
+    eval mode in fp32 and train mode in fp64 against the reference's autograd."""
+    _, scores, uniforms = ofd.fd_inputs()
+    x0 = torch.from_numpy(G["fwd_x"])
+    masks = oinit.drop_masks_2d(int(G["fwd_mask_seed"]), x0.shape[0], *x0.shape[2:])
+    for tag, train, dtype, tol in (("eval", False, torch.float32, 2e-4), ("train64", True, torch.float64, 1e-5)):
+        sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in oinit.dual_decoder_2d_state(int(G["fwd_state_seed"])).items()}
+        for k, v in sd.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        x = x0.clone().to(dtype).requires_grad_(True)
+        o1, o2 = ofd.dual_decoder_2d_dropout(sd, x, [0, 1, 2, 3, 4], scores, True, uniforms, [1] * 5, train=train, drop=masks)
+        g = torch.Generator().manual_seed(int(G["bwd_cot_seed"]))
+        loss = sum((o * torch.randn(o.shape, generator=g).to(dtype)).sum() for o in (o1, o2))
+        loss.backward()
+        assert _relerr(o1.detach().numpy(), G["bwd_%s_logits1" % tag]) < tol
+        assert _relerr(x.grad.numpy(), G["bwd_%s_dx" % tag]) < 10 * tol
+        for i, n in enumerate(G["bwd_pick_names"]):
+            assert _relerr(sd[str(n)].grad.numpy(), G["bwd_%s_grad_pick%d" % (tag, i)]) < 10 * tol, (tag, n)
