@@ -29,7 +29,7 @@ def get_current_consistency_weight(epoch, args):            # train_ours_2D.py:3
 DEFAULT_ARGS = dict(base_lr=0.01, batch_size=24, labeled_bs=12, max_iterations=30000, num_classes=4,
                     consistency=1.0, consistency_rampup=50.0, noise_mag=10.0, epi=6.0, topk1=0.1,
                     adv_noise=True, adv_losstype="kl", vat_iters=1, vat_sign=False, nms=1,
-                    momentum=0.9, weight_decay=1e-4)
+                    momentum=0.9, weight_decay=1e-4, dropout=False, comp_drop=False)
 
 
 class FusedSGD:
@@ -134,6 +134,8 @@ class ChapStep:
         self.world_size = world_size
         self.grad_sync = None                   # parallel.DataParallelSync (world_size > 1)
         self._graph = None
+        self.sim_score = None                   # --dropout: per-level channel scores [C_l] (gradsim.get_sim(), absent upstream);
+                                                # None / all-zero = the Dropout2d pair (FilterDropout.py:71-73)
         # second gradient bucket: the VAT branch accumulates here, so it can run on its own stream beside the
         # BCP branch (and, data-parallel, its all-reduce overlaps); the fused SGD sums both buckets
         n = model.flat_buffers()[1].numel()
@@ -292,9 +294,40 @@ class ChapStep:
             model._exec._capture_sides = {}
         if vat_loss is None:
             vat_loss = torch.zeros(1, dtype=torch.float32, device=volume_batch.device)
+        out = {"mix_losses": losses, "vat_loss": vat_loss}
+        if a["dropout"]:
+            out["fp_losses"] = self._fp_branch(uimg_ab, pseudo_outputs1, pseudo_outputs2, inject, capturing)
         if update:
             self.exchange_and_update()
-        return {"mix_losses": losses, "vat_loss": vat_loss}
+        return out
+
+    def _fp_branch(self, uimg_ab, pseudo1, pseudo2, inject, capturing):
+        """"2) fp" of the loop (train_ours_2D.py:359-365, default off): both decoders on the channel-perturbed features
+        (DualDecoder.forward(dropout=True)), cross-entropy against the other head's pseudo labels, weighted with the
+        consistency weight like the VAT term (:378).  Upstream compares the 1.5 U logits with U labels (a shape error) and
+        reads the scores from the absent grad.GradSim: here every output row is paired with its own sample's pseudo label,
+        cat(pseudo, pseudo[U/2:]), and the scores are `self.sim_score`.  Runs after the VAT branch on the main stream
+        and accumulates into the second gradient bucket; eager only (the weight is applied from the host)."""
+        if capturing:
+            raise NotImplementedError("chap_amd: the dropout (fp_loss) branch runs eagerly (host-side consistency weight)")
+        a, model = self.args, self.model
+        if self.dims != 2:
+            raise NotImplementedError("chap_amd: the dropout (fp_loss) branch exists for the 2D DualDecoder only, as upstream")
+        U = uimg_ab.shape[0]
+        cw = get_current_consistency_weight(self.iter_num // 150, a)
+        o1, o2 = model(uimg_ab, False, True, [0, 1, 2, 3, 4], inject.get("sim_score", self.sim_score), a["comp_drop"],
+                       drop_masks=inject.get("drop_FP"), drop_uniforms=inject.get("fp_uniforms"),
+                       drop_branches=inject.get("fp_branches"), grad_buffer=self.grad2)
+        t1, t2 = torch.cat((pseudo1, pseudo1[U // 2:])), torch.cat((pseudo2, pseudo2[U // 2:]))
+        losses, ds = [], []
+        for o, t in ((o1, t2), (o2, t1)):
+            l3, acc = ops.mix_loss_fwd(o, t, None, None, 1.0, 0.0, k_dice=0.0, k_ce=1.0)        # mean cross-entropy
+            d = torch.empty_like(o)
+            ops.mix_loss_bwd(o, t, None, None, 1.0, 0.0, acc, d, gscale=cw, k_dice=0.0, k_ce=1.0)
+            losses.append(l3[0:1])
+            ds.append(d)
+        torch.autograd.backward([o1, o2], ds)
+        return losses
 
     def step(self, volume_batch, label_batch, box_yx=None, inject=None):
         self._hw = tuple(volume_batch.shape[2:])
@@ -307,6 +340,8 @@ class ChapStep:
     def capture(self, volume_batch, label_batch, warmup=3):
         """Capture device_step() into one HIP graph over static input buffers; afterwards call
         replay(volume_batch, label_batch)."""
+        if self.args["dropout"]:
+            raise NotImplementedError("chap_amd: the dropout (fp_loss) branch runs eagerly (host-side consistency weight)")
         self._hw = tuple(volume_batch.shape[2:])
         self._static_v = volume_batch.clone()
         self._static_l = label_batch.clone()

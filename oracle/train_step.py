@@ -226,13 +226,30 @@ def iteration(sd, moms, volume_batch, label_batch, box_yx, iter_num, lr, args=No
         vat_loss, _ = vat2d(model_fn, uimg_ab, soft1, soft2, diff, d0, a["noise_mag"], a["epi"], a["vat_iters"], a["vat_sign"])
     else:
         vat_loss = torch.zeros((), device=volume_batch.device)
-    loss = bcp_loss + cw * vat_loss
+    fp_loss = torch.zeros((), device=volume_batch.device)
+    fp_terms = None
+    if a.get("dropout"):
+        # "2) fp" (train_ours_2D.py:359-365): both decoders on cat(features, channel-perturbed features of the second half).
+        # Upstream compares these 1.5 U logits with the U pseudo labels (a shape error) and takes the scores from the absent
+        # grad.GradSim; here every output row is paired with its own sample's pseudo label -- cat(pseudo, pseudo[U/2:]) --
+        # and the scores are an input (all-zero scores = the Dropout2d pair of FilterDropout.py:71-73).  PARITY UNPINNED.
+        from . import filter_dropout as ofd
+        U = uimg_ab.shape[0]
+        ctx = nets.Ctx(True, inject.get("drop_FP"), True)
+        feats = nets.encoder_2d(sd, uimg_ab, ctx)
+        f1, f2 = ofd.perform_dropout(feats, [0, 1, 2, 3, 4], inject.get("sim_score"), a.get("comp_drop", False),
+                                     inject["fp_uniforms"], inject.get("fp_branches"))
+        o1fp, o2fp = nets.decoder_2d(sd, "decoder1", f1, ctx), nets.decoder_2d(sd, "decoder2", f2, ctx)
+        t1, t2 = torch.cat((arg1, arg1[U // 2:])), torch.cat((arg2, arg2[U // 2:]))
+        fp_terms = (F.cross_entropy(o1fp, t2), F.cross_entropy(o2fp, t1))
+        fp_loss = fp_terms[0] + fp_terms[1]
+    loss = bcp_loss + cw * (fp_loss + vat_loss)
     names = [k for k, v in sd.items() if v.is_floating_point() and v.requires_grad]
     grads = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
     grads = [g if g is not None else torch.zeros_like(sd[k]) for g, k in zip(grads, names)]
     sgd_step([sd[k] for k in names], grads, [moms[k] for k in names], lr, a["momentum"], a["weight_decay"])
     return dict(losses=[m1, m2, m3, m4], vat_loss=vat_loss.detach(), bcp_loss=bcp_loss.detach(), loss=loss.detach(),
-                grads=dict(zip(names, grads)))
+                grads=dict(zip(names, grads)), fp_losses=None if fp_terms is None else [t.detach() for t in fp_terms])
 
 
 def dice_loss_std(soft, target, n_classes, smooth=1e-5):

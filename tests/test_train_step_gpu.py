@@ -23,6 +23,27 @@ def cl_masks(masks):
     return {k: v.permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(DEV) for k, v in masks.items()}
 
 
+def update_agreement(sd, state, after):
+    """How well one SGD update agrees with the oracle's, as a whole: (relative L2 error over all parameters, smallest
+    per-tensor cosine, its key).  Conv biases in front of a train-mode BatchNorm are left out of the cosine: their true
+    gradient is exactly zero, what both sides hold there is rounding noise."""
+    num = den = 0.0
+    cos_min, cos_key = 1.0, None
+    for k, v in sd.items():
+        if not v.is_floating_point() or k.endswith(("running_mean", "running_var")):
+            continue
+        ug = (after[k].cpu().double() - state[k].double()).flatten()
+        uo = (v.detach().double() - state[k].double()).flatten()
+        num += float(((ug - uo) ** 2).sum())
+        den += float((uo ** 2).sum())
+        if k.endswith(("conv_conv.0.bias", "conv_conv.4.bias")) or float(uo.norm()) == 0:
+            continue
+        c = float((ug * uo).sum() / (ug.norm() * uo.norm() + 1e-300))
+        if c < cos_min:
+            cos_min, cos_key = c, k
+    return (num / den) ** 0.5, cos_min, cos_key
+
+
 def test_iteration_matches_oracle():
     B, lbs, H, W = 8, 4, 64, 64
     U = B - lbs
@@ -177,21 +198,62 @@ def test_ablation_iteration_matches_oracle():
     # 3 % .. 20 % of the tensor's largest update from run to run, while the update as a whole is stable: over 8 repetitions
     # (tests/perf/ablation_tol_probe.py) global relative L2 error 0.006 .. 0.008, smallest per-tensor cosine 0.9991.
     assert worst < 0.5, (worst, worst_key)
-    num = den = 0.0
-    cos_min, cos_key = 1.0, None
-    for k, v in sd.items():
-        if not v.is_floating_point() or k.endswith(("running_mean", "running_var")):
-            continue
-        ug = (after[k].cpu().double() - state[k].double()).flatten()
-        uo = (v.detach().double() - state[k].double()).flatten()
-        num += float(((ug - uo) ** 2).sum())
-        den += float((uo ** 2).sum())
-        if float(uo.norm()) > 0:
-            c = float((ug * uo).sum() / (ug.norm() * uo.norm() + 1e-300))
-            if c < cos_min:
-                cos_min, cos_key = c, k
-    assert (num / den) ** 0.5 < 0.03, (num / den) ** 0.5
+    rel_l2, cos_min, cos_key = update_agreement(sd, state, after)
+    assert rel_l2 < 0.03, rel_l2
     assert cos_min > 0.995, (cos_min, cos_key)
     assert step.iter_num == it0 + 1
     with pytest.raises(NotImplementedError):
         step.capture(vol.to(DEV), lab.to(DEV))
+
+
+def test_iteration_with_channel_dropout_matches_oracle():
+    """args['dropout'] (train_ours_2D.py:359-365, default off): the fp_loss term on the channel-perturbed features -- forward,
+    cross-entropy against cat(pseudo, pseudo[U/2:]), backward into the second gradient bucket, one SGD step -- against the
+    oracle with the same scripted draws.  VAT is switched off here so that the fp term is what the update shows."""
+    from oracle import filter_dropout as ofd
+    B, lbs, H, W = 8, 4, 64, 64
+    U = B - lbs
+    args = dict(labeled_bs=lbs, batch_size=B, vat_iters=1, dropout=True, adv_noise=False)
+    state = oinit.dual_decoder_2d_state(505)
+    vol, lab = ots.synthetic_batch(2468, lbs, U, H, W)
+    _, scores, uniforms = ofd.fd_inputs(B=U)
+    inj_cpu = {"drop_A": oinit.drop_masks_2d(1, U, H, W), "drop_B": oinit.drop_masks_2d(2, lbs // 2 + U // 2, H, W),
+               "drop_FP": oinit.drop_masks_2d(6, U, H, W), "fp_uniforms": uniforms, "sim_score": scores}
+    box = (5, 9)
+    it0 = 3000                                                   # consistency weight 0.165: the fp term matters
+    sd = {k: v.clone() for k, v in state.items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+            v.requires_grad_(True)
+    moms = {k: torch.zeros_like(v) for k, v in sd.items() if v.requires_grad}
+    ref = ots.iteration(sd, moms, vol, lab, box, iter_num=it0, lr=0.01, args=args, inject=inj_cpu)
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train()
+    m.load_state_dict(state, strict=True)
+    step = ChapStep(m, args)
+    step.iter_num = it0
+    inj = {k: (cl_masks(v) if k.startswith("drop") else v) for k, v in inj_cpu.items()}
+    out = step.step(vol.to(DEV), lab.to(DEV), box_yx=box, inject=inj)
+    torch.cuda.synchronize()
+    for got, want in zip(out["fp_losses"], ref["fp_losses"]):
+        assert relerr(got.cpu(), want.reshape(1)) < 2e-4
+    for got, want in zip(out["mix_losses"], ref["losses"]):
+        assert relerr(got.cpu(), torch.stack([w.detach() for w in want])) < 2e-4
+    after = m.state_dict()
+    rel_l2, cos_min, cos_key = update_agreement(sd, state, after)
+    assert rel_l2 < 0.03, rel_l2
+    assert cos_min > 0.995, (cos_min, cos_key)
+    # the update must really contain the fp term: without it the same step lands somewhere else
+    m0 = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train()
+    m0.load_state_dict(state, strict=True)
+    step0 = ChapStep(m0, dict(args, dropout=False))
+    step0.iter_num = it0
+    step0.step(vol.to(DEV), lab.to(DEV), box_yx=box, inject=inj)
+    k = "decoder1.up4.conv.conv_conv.4.weight"
+    d_fp = (after[k] - m0.state_dict()[k]).abs().max().item()
+    upd = (after[k].cpu() - state[k]).abs().max().item()
+    assert d_fp > 0.02 * upd, (d_fp, upd)
+    # BN running statistics also saw the perturbed pass (a plain train-mode forward upstream)
+    for k in ("encoder.in_conv.conv_conv.1.running_mean", "decoder2.up4.conv.conv_conv.5.running_var"):
+        assert relerr(after[k].cpu(), sd[k]) < 1e-3, k
+    with pytest.raises(NotImplementedError):
+        ChapStep(DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train(), args).capture(vol.to(DEV), lab.to(DEV))
