@@ -24,6 +24,7 @@ def _worker(rank, world, port, out):
     b1 += torch.randn(n, generator=g)   # "VAT backward" (concurrent branch)
     sync.start()
     sync.wait()
+    assert float(b1.abs().max()) == 0.0   # bucket 1 was folded into bucket 0 before the exchange (half the bytes on the wire)
     total = (b0 + b1) / world           # what the fused SGD consumes: (grad + grad2) * grad_scale
     torch.save(total, os.path.join(out, "r%d.pt" % rank))
     dist.destroy_process_group()
