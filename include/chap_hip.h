@@ -21,6 +21,14 @@
  * "Lazy activation".  A BatchNorm'd conv output is stored RAW (pre-BN).  Consumers apply
  *     a = keep * keep_scale * chan_mul[n][c] * leaky(scale[c] * raw + shift[c], slope)
  * while loading (chap_src_t), so the normalised/activated tensor is never written to HBM.
+ *
+ * ABI versions (chap_abi_version(), checked by the binding when the library is loaded)
+ *   1  the training iteration: convolutions, weight gradients, BatchNorm, pooling / up-sampling, losses, VAT and BCP
+ *      helpers, largest connected component, fused SGD
+ *   2  chap_mix_loss_*: k_dice / k_ce weights, optional mask and target_b; chap_ensemble_argmax,
+ *      chap_window_accumulate, chap_window_finalize (the inference callers)
+ *   3  chap_sample_channel_sum, chap_channel_drop, chap_fold_perturbed (channel-level perturbation); add-combine
+ *      (combine = 1) also for 2D k3 s1 in chap_conv_fwd / chap_wgrad
  */
 #ifndef CHAP_HIP_H
 #define CHAP_HIP_H
