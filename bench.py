@@ -106,12 +106,12 @@ def dominant_kernel_roofline(model, dtype, N, H):
     out = torch.empty_like(x)
     w = torch.randn(16, 16, 3, 3, device=dev) / 12
     scale, shift = torch.rand(16, device=dev) + 0.5, torch.randn(16, device=dev) * 0.1
-    stats = torch.zeros(8, 2, 16, device=dev)
+    stats = ops.stats_buffer(16, dev)
     wp = ops.pack_weights(w, L.PACK_CONV_FWD, dtype, 16, 16, 9)
     src = ops.Lazy(x, scale, shift, True, 0.01)
 
     def launch():
-        ops.conv_fwd([src], wp, None, 16, out, grid=(N, 1, H, H), in_dims=(1, H, H), ksize=3, stride=1, dims=2, stats=stats, stats_reps=8)
+        ops.conv_fwd([src], wp, None, 16, out, grid=(N, 1, H, H), in_dims=(1, H, H), ksize=3, stride=1, dims=2, stats=stats)
 
     for _ in range(5):
         launch()
@@ -148,12 +148,12 @@ def dominant_kernel_roofline_3d(dtype, N, sp):
     out = torch.empty_like(x)
     w = torch.randn(16, 16, 3, 3, 3, device=dev) / 20
     scale, shift = torch.rand(16, device=dev) + 0.5, torch.randn(16, device=dev) * 0.1
-    stats = torch.zeros(8, 2, 16, device=dev)
+    stats = ops.stats_buffer(16, dev)
     wp = ops.pack_weights(w, L.PACK_CONV_FWD, dtype, 16, 16, 27)
     src = ops.Lazy(x, scale, shift, True, 0.0)
 
     def launch():
-        ops.conv_fwd([src], wp, None, 16, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=3, stats=stats, stats_reps=8)
+        ops.conv_fwd([src], wp, None, 16, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=3, stats=stats)
 
     for _ in range(3):
         launch()

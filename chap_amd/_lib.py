@@ -11,7 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libchap_hip.so")
 
 F32, BF16 = 0, 1
-ACT_BWD_REPS = 32          # CHAP_ACT_BWD_REPS
+STATS_MAX_SLOTS, STATS_HDR = 1024, 4          # CHAP_STATS_MAX_SLOTS, CHAP_STATS_HDR
+ACT_BWD_SLOTS = 1024                           # CHAP_ACT_BWD_SLOTS
+LOSS_SLOTS, CHANSUM_SLOTS, L2NORM_SLOTS = 512, 512, 256
 PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_DECONV_FWD, PACK_DECONV_DGRAD, PACK_DOWN_DGRAD = range(5)
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -29,7 +31,7 @@ class ConvParams(C.Structure):
                 ("wpacked", _vp), ("bias", _vp), ("out", _vp),
                 ("Cout", _i32), ("out_ld", _i32), ("out_coff", _i32), ("out_mode", _i32), ("out_Cn", _i32),
                 ("out_planar", _i32), ("out_f32", _i32),
-                ("stats", _vp), ("stats_reps", _i32), ("dtype", _i32)]
+                ("stats", _vp), ("stats_shift", _vp), ("dtype", _i32)]
 
 
 class PackParams(C.Structure):
@@ -43,7 +45,7 @@ class PackEntry(C.Structure):
 
 
 class ConvC1Params(C.Structure):
-    _fields_ = [("x", _vp), ("w", _vp), ("bias", _vp), ("out", _vp), ("stats", _vp), ("stats_reps", _i32),
+    _fields_ = [("x", _vp), ("w", _vp), ("bias", _vp), ("out", _vp), ("stats", _vp), ("stats_shift", _vp),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("dims", _i32), ("Cout", _i32), ("dtype", _i32)]
 
 
@@ -61,7 +63,7 @@ class WgradParams(C.Structure):
 
 
 class BnFinalizeParams(C.Structure):
-    _fields_ = [("stats", _vp), ("stats_reps", _i32), ("gamma", _vp), ("beta", _vp),
+    _fields_ = [("stats", _vp), ("stats_shift", _vp), ("Clog", _i32), ("gamma", _vp), ("beta", _vp),
                 ("running_mean", _vp), ("running_var", _vp), ("num_batches_tracked", _vp),
                 ("scale", _vp), ("shift", _vp), ("mean", _vp), ("invstd", _vp),
                 ("C", _i32), ("count", _f32), ("eps", _f32), ("momentum", _f32)]
@@ -99,7 +101,7 @@ class PlanarToClParams(C.Structure):
 
 
 class ChanSumParams(C.Structure):
-    _fields_ = [("r", Src), ("out", _vp), ("npix", _i64), ("pix_per_sample", _i64), ("dtype", _i32)]
+    _fields_ = [("r", Src), ("out", _vp), ("npix", _i64), ("pix_per_sample", _i64), ("dtype", _i32), ("ws", _vp)]
 
 
 class ClToPlanarParams(C.Structure):
@@ -109,7 +111,7 @@ class ClToPlanarParams(C.Structure):
 class MixLossParams(C.Structure):
     _fields_ = [("logits", _vp), ("target_a", _vp), ("target_b", _vp), ("mask", _vp), ("w_a", _f32), ("w_b", _f32),
                 ("acc", _vp), ("loss", _vp), ("dlogits", _vp), ("gscale", _f32), ("accumulate", _i32),
-                ("N", _i32), ("C", _i32), ("P", _i32), ("smooth", _f32), ("k_dice", _f32), ("k_ce", _f32)]
+                ("N", _i32), ("C", _i32), ("P", _i32), ("smooth", _f32), ("k_dice", _f32), ("k_ce", _f32), ("gscale_dev", _vp)]
 
 
 class PseudoParams(C.Structure):
@@ -119,7 +121,7 @@ class PseudoParams(C.Structure):
 
 class KlParams(C.Structure):
     _fields_ = [("logits", _vp * 2), ("target", _vp * 2), ("loss", _vp), ("dlogits", _vp * 2),
-                ("gscale", _f32), ("gscale_dev", _vp), ("N", _i32), ("C", _i32), ("P", _i32)]
+                ("gscale", _f32), ("gscale_dev", _vp), ("N", _i32), ("C", _i32), ("P", _i32), ("mode", _i32), ("ws", _vp)]
 
 
 class EnsembleParams(C.Structure):
@@ -187,6 +189,10 @@ class DiffMaskParams(C.Structure):
                 ("N", _i32), ("H", _i32), ("W", _i32), ("scale", _i32), ("topk", _f32)]
 
 
+class GradSimParams(C.Structure):
+    _fields_ = [("gl", _vp), ("gu", _vp), ("score", _vp), ("C", _i32), ("K", _i32), ("ema", _f32)]
+
+
 class SgdParams(C.Structure):
     _fields_ = [("param", _vp), ("grad", _vp), ("grad2", _vp), ("mom", _vp), ("lr", _vp), ("momentum", _f32), ("weight_decay", _f32),
                 ("grad_scale", _f32), ("n", _i64), ("zero_grad", _i32)]
@@ -205,7 +211,7 @@ _SIGS = {  # name -> (restype, params struct or None)
     "chap_box_mix": BoxMixParams, "chap_box_mask": BoxMaskParams, "chap_largest_cc": LccParams,
     "chap_diff_mask": DiffMaskParams, "chap_sgd_step": SgdParams,
     "chap_sample_channel_sum": SampleChanSumParams, "chap_channel_drop": ChannelDropParams,
-    "chap_fold_perturbed": FoldParams,
+    "chap_fold_perturbed": FoldParams, "chap_grad_sim": GradSimParams,
 }
 _SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParams, "chap_wgrad_ws": WgradParams,
              "chap_lcc_ws": LccParams}
@@ -213,7 +219,7 @@ _SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParam
 _lib = None
 
 
-ABI_VERSION = 3            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
+ABI_VERSION = 4            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
 
 
 class ChapError(RuntimeError):
@@ -230,16 +236,17 @@ def lib():
         # The library is linked against the system ROCm runtime while PyTorch ships its own copy: the HIP runtime
         # PyTorch uses has to be initialised BEFORE this library is loaded (observed on the MI355X box: loaded the
         # other way round, the first kernel launch fails with "no ROCm-capable device is detected").
-        try:
-            import torch
-            if torch.cuda.is_available():
-                torch.cuda.init()
-                torch.cuda.current_stream()
-        except Exception:
-            pass
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()               # an error here is the load-order problem itself: let it propagate
+            torch.cuda.current_stream()
         L = C.CDLL(LIB_PATH)
         L.chap_last_error.restype = C.c_char_p
         L.chap_abi_version.restype = C.c_int
+        got = L.chap_abi_version()
+        if got != ABI_VERSION:
+            raise ChapError("libchap_hip.so has ABI version %d, this binding mirrors include/chap_hip.h version %d: rebuild "
+                            "(`make -C chap_amd/csrc`) -- a stale library would be driven through mismatching structs" % (got, ABI_VERSION))
         _lib = L
     return _lib
 

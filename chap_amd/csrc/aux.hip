@@ -2,7 +2,8 @@
 // spatial perturbation mask (avg-pool + per-sample top-k by radix select), fused SGD.
 #include "common.h"
 
-// ---- per-sample L2 normalise: (sample, slice) blocks accumulate sum of squares, then scale -------------------
+// ---- per-sample L2 normalise: (sample, slice) blocks write their sum of squares to ss[n][slice] (no atomics); every block of
+// the scale pass re-derives the sample's total from those partials in the same fixed order -> bitwise reproducible
 __global__ __launch_bounds__(256) void l2norm_sumsq_kernel(const float* __restrict__ in, float* __restrict__ ss, int P) {
     __shared__ float red[4];
     const float* x = in + (long)blockIdx.y * P;
@@ -11,21 +12,29 @@ __global__ __launch_bounds__(256) void l2norm_sumsq_kernel(const float* __restri
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(&ss[blockIdx.y], (red[0] + red[1]) + (red[2] + red[3]));
+    if (threadIdx.x == 0) ss[(long)blockIdx.y * CHAP_L2NORM_SLOTS + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 __global__ __launch_bounds__(256) void l2norm_scale_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ ss, int P, float eps) {
-    const float inv = 1.f / (sqrtf(ss[blockIdx.y]) + eps);
+    __shared__ float tot;
+    if (threadIdx.x < 64) {
+        double t = 0.0;
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += 64) t += (double)ss[(long)blockIdx.y * CHAP_L2NORM_SLOTS + b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (threadIdx.x == 0) tot = (float)t;
+    }
+    __syncthreads();
+    const float inv = 1.f / (sqrtf(tot) + eps);
     const float* x = in + (long)blockIdx.y * P;
     float* o = out + (long)blockIdx.y * P;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < P; i += gridDim.x * 256) o[i] = x[i] * inv;
 }
 extern "C" int chap_l2_normalize(const chap_l2norm_params* p, void* stream) {
-    CHAP_CHECK_ARG(p && p->in && p->out && p->ws && p->N > 0 && p->P > 0, "chap_l2_normalize: bad argument (ws = N floats)");
+    CHAP_CHECK_ARG(p && p->in && p->out && p->ws && p->N > 0 && p->P > 0, "chap_l2_normalize: bad argument (ws = N * CHAP_L2NORM_SLOTS floats)");
     hipStream_t s = (hipStream_t)stream;
     int bx = (p->P + 256 * 8 - 1) / (256 * 8);
-    if (bx > 256) bx = 256;
+    if (bx > CHAP_L2NORM_SLOTS) bx = CHAP_L2NORM_SLOTS;
     if (bx < 1) bx = 1;
-    (void)hipMemsetAsync(p->ws, 0, sizeof(float) * p->N, s);
     hipLaunchKernelGGL(l2norm_sumsq_kernel, dim3(bx, p->N), dim3(256), 0, s, p->in, p->ws, p->P);
     hipLaunchKernelGGL(l2norm_scale_kernel, dim3(bx, p->N), dim3(256), 0, s, p->in, p->out, (const float*)p->ws, p->P, p->eps);
     CHAP_LAUNCH_CHECK("chap_l2_normalize");
@@ -235,6 +244,28 @@ extern "C" int chap_sgd_step(const chap_sgd_params* p, void* stream) {
     const int nb = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(sgd_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_sgd_step");
+    return CHAP_OK;
+}
+
+// ---- GradSim: per output channel, cosine similarity of two gradients of one conv kernel (rows of K contiguous floats) ----
+__global__ __launch_bounds__(256) void gradsim_kernel(const chap_gradsim_params P) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= P.C) return;
+    const float* a = P.gl + (long)c * P.K;
+    const float* b = P.gu + (long)c * P.K;
+    double dot = 0.0, na = 0.0, nb = 0.0;
+    for (int k = lane; k < P.K; k += 64) { const double x = a[k], y = b[k]; dot += x * y; na += x * x; nb += y * y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { dot += __shfl_xor(dot, o, 64); na += __shfl_xor(na, o, 64); nb += __shfl_xor(nb, o, 64); }
+    if (lane == 0) {
+        const float sim = (float)(dot / (sqrt(na) * sqrt(nb) + 1e-12));
+        P.score[c] = P.ema * P.score[c] + (1.f - P.ema) * sim;
+    }
+}
+extern "C" int chap_grad_sim(const chap_gradsim_params* p, void* stream) {
+    CHAP_CHECK_ARG(p && p->gl && p->gu && p->score && p->C > 0 && p->K > 0, "chap_grad_sim: bad argument");
+    hipLaunchKernelGGL(gradsim_kernel, dim3((p->C + 3) / 4), dim3(256), 0, (hipStream_t)stream, *p);
+    CHAP_LAUNCH_CHECK("chap_grad_sim");
     return CHAP_OK;
 }
 

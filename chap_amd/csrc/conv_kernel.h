@@ -12,7 +12,7 @@
 // from LDS, then transformed (lazy activation: BN affine + LeakyReLU + dropout) and written to the
 // other LDS buffer -- one barrier per item.  Output tile = TH x 16 pixels of one z-plane (TH = 4*MR,
 // wave w owns rows [w*MR, w*MR+MR)) x 16*NT output channels.  BatchNorm statistics are kept in
-// registers across tiles and flushed with ONE float atomic per channel per block.
+// registers across tiles and flushed once per block into that block's partial slot (no atomics).
 #pragma once
 #include "common.h"
 #include <type_traits>
@@ -60,7 +60,7 @@ constexpr int CONV_MAX_AFFINE_C = 1024;            // channels (both sources) wh
 template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ZW = false>
 __host__ __device__ constexpr size_t conv_lds_fixed_bytes(int NT) {
     return 2 * ((size_t)conv_geom<KS, ST, D3, MR, ZW>::HP * pix_stride<T, KC>() + HALO_DUMMY) * sizeof(T)   // two halo buffers
-           + 2 * 16 * NT * sizeof(float);                                                // block statistics
+           + 4 * 2 * 16 * NT * sizeof(float);                                            // block statistics: [wave][S | Q][16*NT]
 }
 
 // Weights that do not fit LDS whole are staged per item (one K-chunk: STEPS x NT fragment blocks) through
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     T* halo0 = (T*)smem;
     T* halo1 = halo0 + (size_t)G::HP * PS + HALO_DUMMY;
     float* bstat = (float*)(halo1 + (size_t)G::HP * PS + HALO_DUMMY);
-    float* aff = bstat + 2 * 16 * NT;                       // [2 sources][scale | shift][CONV_MAX_AFFINE_C/2]
+    float* aff = bstat + 4 * 2 * 16 * NT;                   // [2 sources][scale | shift][CONV_MAX_AFFINE_C/2]
     T* wlds = (T*)(aff + 2 * CONV_MAX_AFFINE_C);            // WLDS: all weights; staged mode: two buffers of one K-chunk's weights
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -505,11 +505,13 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     }
 
     f32x4 acc[MR][NT];
-    float ssum[NT][4], ssq[NT][4], bj[NT][4];
+    float ssum[NT][4], ssq[NT][4], bj[NT][4], cj[NT][4];        // cj: shift of the statistics (moments of v - c)
     // bias: all loads first (index clamped, no branch, no use in between), the selects afterwards -- a use right
     // behind each load makes the compiler wait for it (and for every prefetch issued above) NT*4 times in a row
     {
         const float* bsrc = P.bias ? P.bias : (const float*)P.wpacked;          // wave-uniform; any valid address when there is no bias
+        const bool has_shift = P.stats != nullptr && P.stats_shift != nullptr;
+        const float* csrc = has_shift ? P.stats_shift : (const float*)P.wpacked;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int nl = (nt0 + t) * 16 + 4 * g;
@@ -518,6 +520,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
             for (int j = 0; j < 4; ++j) {
                 ssum[t][j] = 0.f; ssq[t][j] = 0.f;
                 bj[t][j] = bsrc[(P.bias && nl + j < P.Cout) ? cb + j : 0];
+                cj[t][j] = csrc[(has_shift && nl + j < P.Cout) ? cb + j : 0];
             }
         }
     }
@@ -555,12 +558,15 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     for (int t = 0; t < NT; ++t) {
         const int nl = (nt0 + t) * 16 + 4 * g;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bj[t][j] = (P.bias && nl + j < P.Cout) ? bj[t][j] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            bj[t][j] = (P.bias && nl + j < P.Cout) ? bj[t][j] : 0.f;
+            cj[t][j] = (P.stats != nullptr && P.stats_shift != nullptr && nl + j < P.Cout) ? cj[t][j] : 0.f;
+        }
     }
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(bj[t][j]));   // land the bias loads here, not behind the first prefetch of the item loop
+        for (int j = 0; j < 4; ++j) { asm volatile("" : "+v"(bj[t][j])); asm volatile("" : "+v"(cj[t][j])); }   // land the bias loads here, not behind the first prefetch of the item loop
     const bool do_stats = P.stats != nullptr;
     const int SD2 = (P.dims == 3) ? 2 : 1;
     // per-lane output offsets relative to the tile origin (elements), one per (t): row term added per m
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
                         for (int j = 0; j < 4; ++j) v[j] = acc[m][t][j] + bj[t][j];
                         if (!valid) continue;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { ssum[t][j] += v[j]; ssq[t][j] += v[j] * v[j]; }
+                        for (int j = 0; j < 4; ++j) { const float vs = v[j] - cj[t][j]; ssum[t][j] += vs; ssq[t][j] += vs * vs; }
                         const long oi = o0 + row * orow + zw_off + ooff[t];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) if (nl + j < P.Cout) {
@@ -715,7 +721,7 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
                             for (int j = 0; j < 4; ++j) v[j] = acc[m][t][j] + bj[t][j];
                             if (do_stats) {
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) { const float vs = valid ? v[j] : 0.f; ssum[t][j] += vs; ssq[t][j] += vs * vs; }
+                                for (int j = 0; j < 4; ++j) { const float vs = valid ? v[j] - cj[t][j] : 0.f; ssum[t][j] += vs; ssq[t][j] += vs * vs; }
                             }
                             if (CHAP_ABLATE & 8) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
                             const unsigned oi = (unsigned)(row * orow + zw_off + ooff[t]);
@@ -743,29 +749,29 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
     }
 
     CHAP_STAMP_P(4);
-    // ---- BatchNorm statistics: registers -> 16-lane shuffle -> LDS -> one atomic per channel per block
+    // ---- BatchNorm statistics: registers -> 16-lane DPP reduce -> LDS row of this wave -> the four rows summed in a fixed
+    // order -> this block's partial slot (plain stores: no atomics anywhere, chap_bn_finalize sums the slots in a fixed
+    // order, so the statistics are bitwise reproducible for a given launch geometry)
     if (do_stats) {
-        for (int i = threadIdx.x; i < 2 * 16 * NT; i += 256) bstat[i] = 0.f;
-        __syncthreads();
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float s = row16_sum(ssum[t][j]), q = row16_sum(ssq[t][j]);
                 if (px == 0) {
-                    atomicAdd(&bstat[t * 16 + 4 * g + j], s);
-                    atomicAdd(&bstat[16 * NT + t * 16 + 4 * g + j], q);
+                    bstat[(wave * 2 + 0) * 16 * NT + t * 16 + 4 * g + j] = s;
+                    bstat[(wave * 2 + 1) * 16 * NT + t * 16 + 4 * g + j] = q;
                 }
             }
         }
         __syncthreads();
-        const int rep = P.stats_reps > 1 ? (blockIdx.x % P.stats_reps) : 0;
-        const int Cs = P.out_mode == 1 ? P.out_Cn : P.Cout;       // statistics are per REAL channel
-        float* st = P.stats + (long)rep * 2 * Cs;
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(int*)P.stats = (int)gridDim.x;      // header: slots in use
+        float* st = P.stats + CHAP_STATS_HDR + (long)blockIdx.x * 2 * P.Cout;      // slot rows are indexed by the LOGICAL channel (a transposed conv's sub-lattices are folded by the finalize)
         for (int i = threadIdx.x; i < 2 * 16 * NT; i += 256) {
             const int which = i / (16 * NT), k = i % (16 * NT);
             const int nl = nt0 * 16 + k;
-            if (nl < P.Cout) atomicAdd(&st[which * Cs + (P.out_mode == 1 ? nl % P.out_Cn : nl)], bstat[i]);
+            const float v = (bstat[(0 * 2 + which) * 16 * NT + k] + bstat[(1 * 2 + which) * 16 * NT + k]) + (bstat[(2 * 2 + which) * 16 * NT + k] + bstat[(3 * 2 + which) * 16 * NT + k]);
+            if (nl < P.Cout) st[which * P.Cout + nl] = v;
         }
     }
     CHAP_STAMP_P(5);

@@ -1,8 +1,26 @@
 // Segmentation-loss kernels on fp32 planar logits [N][C][P] (C <= 8): one thread per pixel keeps
-// the C logits in registers, softmax in registers, wave64 shuffle reductions, one float atomic per
-// block and accumulator.  HBM-bound: each logit is read once per pass.
+// the C logits in registers, softmax in registers, wave64 shuffle reductions, one partial row per block and a
+// fixed-order fp64 total (no atomics: bitwise reproducible).  HBM-bound: each logit is read once per pass.
 #include "common.h"
 
+// Fixed-order wave reduction in fp64 (xor butterfly: the same pairing on every run).
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// Row 0 of a [1 + nrows][rl] partial workspace <- fixed-order column sums of rows 1..nrows (one wave per column, fp64).
+// Called by all 256 threads of ONE block; `tot` (shared, rl floats) receives the totals too.  Ends with a barrier.
+__device__ __forceinline__ void sum_partial_rows(float* ws, int nrows, int rl, float* tot) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = wave; i < rl; i += 4) {
+        double t = 0.0;
+        for (int b = lane; b < nrows; b += 64) t += (double)ws[(long)(1 + b) * rl + i];
+        t = wave_sum_f64(t);
+        if (lane == 0) { tot[i] = (float)t; ws[i] = (float)t; }
+    }
+    __syncthreads();
+}
 
 
 template <int C>
@@ -23,9 +41,7 @@ __device__ __forceinline__ void softmax_px(const float* __restrict__ lg, long ba
 template <int C>
 __global__ __launch_bounds__(256) void mix_loss_acc_kernel(const chap_mix_loss_params P_) {
     constexpr int NA = 2 + 3 * C;
-    __shared__ float red[2 * NA];
-    for (int i = threadIdx.x; i < 2 * NA; i += 256) red[i] = 0.f;
-    __syncthreads();
+    __shared__ float red[4][2 * NA];
     float a[2][NA];
 #pragma unroll
     for (int k = 0; k < 2; ++k)
@@ -59,20 +75,23 @@ __global__ __launch_bounds__(256) void mix_loss_acc_kernel(const chap_mix_loss_p
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const float v = wave_sum(a[k][i]);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&red[k * NA + i], v);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k * NA + i] = v;
         }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * NA; i += 256) atomicAdd(&P_.acc[i], red[i]);
+    // this block's partial row (fixed order over the four waves; no atomics): acc[1 + block][2*NA]
+    for (int i = threadIdx.x; i < 2 * NA; i += 256) P_.acc[(long)(1 + blockIdx.x) * 2 * NA + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 
-// mix_loss return triple (train_ours_2D.py:205-216) from the accumulators.
-__global__ void mix_loss_final_kernel(const float* acc, float* loss, int C, float w_a, float w_b, float smooth, float k_dice, float k_ce) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Totals (row 0 of acc, fixed-order sum of the block partials) and the mix_loss return triple (train_ours_2D.py:205-216).
+__global__ __launch_bounds__(256) void mix_loss_final_kernel(float* acc, int nblocks, float* loss, int C, float w_a, float w_b, float smooth, float k_dice, float k_ce) {
+    __shared__ float tot[2 * (2 + 3 * 8)];
     const int NA = 2 + 3 * C;
+    sum_partial_rows(acc, nblocks, 2 * NA, tot);
+    if (threadIdx.x != 0) return;
     float part[2];
     const float w[2] = {w_a, w_b};
     for (int k = 0; k < 2; ++k) {
-        const float* a = acc + k * NA;
+        const float* a = tot + k * NA;
         float dice = 0.f;
         for (int c = 0; c < C; ++c) dice += 1.f - (2.f * a[1 + c] + smooth) / (a[1 + C + c] + a[1 + 2 * C + c] + smooth);
         dice = dice / C * w[k];
@@ -90,6 +109,7 @@ __global__ __launch_bounds__(256) void mix_loss_bwd_kernel(const chap_mix_loss_p
     __syncthreads();
     const long P = P_.P, total = (long)P_.N * P;
     const float w[2] = {P_.w_a, P_.w_b};
+    const float gsc = P_.gscale * (P_.gscale_dev ? *P_.gscale_dev : 1.f);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long n = (unsigned)i / (unsigned)P, pp = (unsigned)i % (unsigned)P;
         float z[C], p[C], lse;
@@ -119,7 +139,7 @@ __global__ __launch_bounds__(256) void mix_loss_bwd_kernel(const chap_mix_loss_p
         for (int c = 0; c < C; ++c) dot += dp[c] * p[c];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float gz = P_.gscale * (kc * dz[c] + kd * p[c] * (dp[c] - dot));
+            const float gz = gsc * (kc * dz[c] + kd * p[c] * (dp[c] - dot));
             float* o = P_.dlogits + n * C * P + c * P + pp;
             *o = P_.accumulate ? *o + gz : gz;
         }
@@ -127,17 +147,19 @@ __global__ __launch_bounds__(256) void mix_loss_bwd_kernel(const chap_mix_loss_p
 }
 
 static int loss_blocks(long total) { long b = (total + 255) / 256; return (int)(b < 2048 ? b : 2048); }
+static int loss_slots(long total) { long b = (total + 255) / 256; return (int)(b < CHAP_LOSS_SLOTS ? b : CHAP_LOSS_SLOTS); }   // kernels that leave one partial row per block
 
 extern "C" int chap_mix_loss_fwd(const chap_mix_loss_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->logits && p->target_a && p->acc && p->loss, "chap_mix_loss_fwd: null argument");
     CHAP_CHECK_ARG(p->C == 4 || p->C == 2, "chap_mix_loss: C=%d (2 or 4 built)", p->C);
-    const int nb = loss_blocks((long)p->N * p->P);
+    CHAP_CHECK_ARG((long)p->N * p->P < (1L << 32), "chap_mix_loss: N*P=%ld exceeds the 32-bit pixel index", (long)p->N * p->P);
+    const int nb = loss_slots((long)p->N * p->P);
     hipStream_t s = (hipStream_t)stream;
     if (p->C == 4) hipLaunchKernelGGL(mix_loss_acc_kernel<4>, dim3(nb), dim3(256), 0, s, *p);
     else hipLaunchKernelGGL(mix_loss_acc_kernel<2>, dim3(nb), dim3(256), 0, s, *p);
     CHAP_LAUNCH_CHECK("chap_mix_loss_fwd");
     const bool dflt = p->k_dice == 0.f && p->k_ce == 0.f;
-    hipLaunchKernelGGL(mix_loss_final_kernel, dim3(1), dim3(64), 0, s, (const float*)p->acc, p->loss, p->C, p->w_a, p->w_b, p->smooth,
+    hipLaunchKernelGGL(mix_loss_final_kernel, dim3(1), dim3(256), 0, s, p->acc, nb, p->loss, p->C, p->w_a, p->w_b, p->smooth,
                        dflt ? 0.5f : p->k_dice, dflt ? 0.5f : p->k_ce);
     CHAP_LAUNCH_CHECK("chap_mix_loss_fwd(final)");
     return CHAP_OK;
@@ -145,6 +167,7 @@ extern "C" int chap_mix_loss_fwd(const chap_mix_loss_params* p, void* stream) {
 extern "C" int chap_mix_loss_bwd(const chap_mix_loss_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->logits && p->target_a && p->acc && p->dlogits, "chap_mix_loss_bwd: null argument");
     CHAP_CHECK_ARG(p->C == 4 || p->C == 2, "chap_mix_loss: C=%d (2 or 4 built)", p->C);
+    CHAP_CHECK_ARG((long)p->N * p->P < (1L << 32), "chap_mix_loss: N*P=%ld exceeds the 32-bit pixel index", (long)p->N * p->P);
     const int nb = loss_blocks((long)p->N * p->P);
     if (p->C == 4) hipLaunchKernelGGL(mix_loss_bwd_kernel<4>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(mix_loss_bwd_kernel<2>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
@@ -181,6 +204,7 @@ extern "C" int chap_pseudo_block(const chap_pseudo_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->logits1 && p->logits2, "chap_pseudo_block: null argument");
     CHAP_CHECK_ARG(p->C == 4 || p->C == 2, "chap_pseudo_block: C=%d (2 or 4 built)", p->C);
     CHAP_CHECK_ARG((p->soft1 == nullptr) == (p->soft2 == nullptr) && (p->arg1 == nullptr) == (p->arg2 == nullptr), "chap_pseudo_block: outputs come in pairs");
+    CHAP_CHECK_ARG((long)p->N * p->P < (1L << 32), "chap_pseudo_block: N*P=%ld exceeds the 32-bit pixel index", (long)p->N * p->P);
     const int nb = loss_blocks((long)p->N * p->P);
     if (p->C == 4) hipLaunchKernelGGL(pseudo_kernel<4>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(pseudo_kernel<2>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
@@ -188,12 +212,15 @@ extern "C" int chap_pseudo_block(const chap_pseudo_params* p, void* stream) {
     return CHAP_OK;
 }
 
-// KL(target || softmax(logits)), mean over N*P, summed over the two heads; gradient wrt logits.
+// VAT distances between the two heads' logits and their targets, with the gradient wrt the logits.
+//   mode 0 (kl):   sum_heads mean_{n,p} KL(target || softmax(logits)) -- one pass (the gradient is local);
+//   mode 1 (dice): sum_heads mean_c [1 - (2 I_c + s) / (Z_c + Y_c + s)],  I = sum p t, Z = sum p^2, Y = sum t^2 over (n, p)
+//                  (the soft Dice of the VAT reference implementations this script family uses for adv_losstype='dice'):
+//                  pass 1 accumulates (I, Z, Y), pass 2 writes the gradient through the softmax.
+// ws rows: [1 + CHAP_LOSS_SLOTS][2 heads][3*C + 1]; the KL partial loss of a block sits in column 0.
 template <int C>
 __global__ __launch_bounds__(256) void kl_kernel(const chap_kl_params P_) {
-    __shared__ float red;
-    if (threadIdx.x == 0) red = 0.f;
-    __syncthreads();
+    __shared__ float red[4];
     const long P = P_.P, total = (long)P_.N * P;
     const float inv = 1.f / (float)total;
     const float gs = P_.gscale * (P_.gscale_dev ? *P_.gscale_dev : 1.f) * inv;
@@ -212,18 +239,119 @@ __global__ __launch_bounds__(256) void kl_kernel(const chap_kl_params P_) {
             }
         }
     }
+    if (!P_.ws) return;
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&red, acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0 && P_.loss) atomicAdd(P_.loss, red * inv);
+    if (threadIdx.x == 0) P_.ws[(long)(1 + blockIdx.x) * 2 * (3 * C + 1)] = (red[0] + red[1]) + (red[2] + red[3]);
 }
+
+template <int C>
+__global__ __launch_bounds__(256) void dice_dist_acc_kernel(const chap_kl_params P_) {
+    constexpr int RH = 3 * C + 1, RL = 2 * RH;
+    __shared__ float red[4][RL];
+    const long P = P_.P, total = (long)P_.N * P;
+    float a[2][3 * C];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 3 * C; ++i) a[h][i] = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = (unsigned)i / (unsigned)P, pp = (unsigned)i % (unsigned)P, base = n * C * P + pp;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float z[C], p[C], lse;
+            softmax_px<C>(P_.logits[h], base, P, z, p, lse);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float t = P_.target[h][base + c * P];
+                a[h][c] += p[c] * t; a[h][C + c] += p[c] * p[c]; a[h][2 * C + c] += t * t;
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 3 * C; ++i) {
+            const float v = wave_sum(a[h][i]);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][h * RH + i] = v;
+        }
+    if (threadIdx.x < 4) { red[threadIdx.x][3 * C] = 0.f; red[threadIdx.x][RH + 3 * C] = 0.f; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < RL; i += 256) P_.ws[(long)(1 + blockIdx.x) * RL + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+
+constexpr float DICE_DIST_SMOOTH = 1e-10f;
+
+// totals -> row 0; loss += the distance (one thread: deterministic)
+__global__ __launch_bounds__(256) void dist_final_kernel(float* ws, int nblocks, int C, int mode, float inv_total, float* loss) {
+    __shared__ float tot[2 * (3 * 8 + 1)];
+    const int RH = 3 * C + 1;
+    sum_partial_rows(ws, nblocks, 2 * RH, tot);
+    if (threadIdx.x != 0 || !loss) return;
+    if (mode == 0) { *loss += tot[0] * inv_total; return; }
+    float d = 0.f;
+    for (int h = 0; h < 2; ++h)
+        for (int c = 0; c < C; ++c) d += (1.f - (2.f * tot[h * RH + c] + DICE_DIST_SMOOTH) / (tot[h * RH + C + c] + tot[h * RH + 2 * C + c] + DICE_DIST_SMOOTH)) / (float)C;
+    *loss += d;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void dice_dist_grad_kernel(const chap_kl_params P_) {
+    constexpr int RH = 3 * C + 1;
+    __shared__ float sa[2 * RH];
+    for (int i = threadIdx.x; i < 2 * RH; i += 256) sa[i] = P_.ws[i];
+    __syncthreads();
+    const long P = P_.P, total = (long)P_.N * P;
+    const float gs = P_.gscale * (P_.gscale_dev ? *P_.gscale_dev : 1.f);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long n = (unsigned)i / (unsigned)P, pp = (unsigned)i % (unsigned)P, base = n * C * P + pp;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!P_.dlogits[h]) continue;
+            float z[C], p[C], lse, dp[C], dot = 0.f;
+            softmax_px<C>(P_.logits[h], base, P, z, p, lse);
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float t = P_.target[h][base + c * P];
+                const float den = sa[h * RH + C + c] + sa[h * RH + 2 * C + c] + DICE_DIST_SMOOTH;
+                dp[c] = (-2.f * t / den + (2.f * sa[h * RH + c] + DICE_DIST_SMOOTH) * 2.f * p[c] / (den * den)) / (float)C;
+                dot += dp[c] * p[c];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) P_.dlogits[h][base + c * P] = gs * p[c] * (dp[c] - dot);
+        }
+    }
+}
+
 extern "C" int chap_kl_fwd_bwd(const chap_kl_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->logits[0] && p->logits[1] && p->target[0] && p->target[1], "chap_kl_fwd_bwd: null argument");
     CHAP_CHECK_ARG(p->C == 4 || p->C == 2, "chap_kl_fwd_bwd: C=%d (2 or 4 built)", p->C);
-    const int nb = loss_blocks((long)p->N * p->P);
-    if (p->C == 4) hipLaunchKernelGGL(kl_kernel<4>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL(kl_kernel<2>, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_kl_fwd_bwd");
+    CHAP_CHECK_ARG(p->mode == 0 || p->mode == 1, "chap_kl_fwd_bwd: mode=%d (0 kl, 1 dice)", p->mode);
+    CHAP_CHECK_ARG(p->ws || (p->mode == 0 && !p->loss), "chap_kl_fwd_bwd: ws is required for the loss value and for the dice distance");
+    const long total = (long)p->N * p->P;
+    CHAP_CHECK_ARG(total < (1L << 32), "chap_kl_fwd_bwd: N*P=%ld exceeds the 32-bit pixel index", total);
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = loss_slots(total);
+    if (p->mode == 0) {
+        if (p->C == 4) hipLaunchKernelGGL(kl_kernel<4>, dim3(nb), dim3(256), 0, s, *p);
+        else hipLaunchKernelGGL(kl_kernel<2>, dim3(nb), dim3(256), 0, s, *p);
+        CHAP_LAUNCH_CHECK("chap_kl_fwd_bwd");
+        if (p->loss) {
+            hipLaunchKernelGGL(dist_final_kernel, dim3(1), dim3(256), 0, s, p->ws, nb, p->C, 0, 1.f / (float)total, p->loss);
+            CHAP_LAUNCH_CHECK("chap_kl_fwd_bwd(final)");
+        }
+        return CHAP_OK;
+    }
+    if (p->C == 4) hipLaunchKernelGGL(dice_dist_acc_kernel<4>, dim3(nb), dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL(dice_dist_acc_kernel<2>, dim3(nb), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(dist_final_kernel, dim3(1), dim3(256), 0, s, p->ws, nb, p->C, 1, 1.f / (float)total, p->loss);
+    if (p->dlogits[0] || p->dlogits[1]) {
+        const int nbg = loss_blocks(total);
+        if (p->C == 4) hipLaunchKernelGGL(dice_dist_grad_kernel<4>, dim3(nbg), dim3(256), 0, s, *p);
+        else hipLaunchKernelGGL(dice_dist_grad_kernel<2>, dim3(nbg), dim3(256), 0, s, *p);
+    }
+    CHAP_LAUNCH_CHECK("chap_kl_fwd_bwd(dice)");
     return CHAP_OK;
 }
 

@@ -9,17 +9,23 @@
 // gfx950 and turned these streaming kernels VALU-bound); entry points reject tensors with >= 2^32 elements.
 typedef unsigned int u32;
 
+// Fixed-order wave reduction in fp64 (xor butterfly: the same pairing on every run).
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // =========================================================================================
 // First conv, Cin = 1, k3 s1 "same" (unet.py:50 with in_chns=1; vnet.py:19 with n_channels=1).
 // One thread per output pixel computes all Cout (<= 32) channels; weights + bias live in LDS.
 template <typename T, bool D3, int CO>
 __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const chap_conv_c1_params P) {
     constexpr int KD = D3 ? 3 : 1, TAPS = KD * 9;
-    __shared__ float ws[CO * TAPS + CO];
-    __shared__ float bstat[2 * CO];
+    __shared__ float ws[CO * TAPS + 2 * CO];
+    __shared__ float bstat[4][2 * CO];
     for (int i = threadIdx.x; i < CO * TAPS; i += 256) ws[i] = P.w[i];
-    for (int i = threadIdx.x; i < CO; i += 256) ws[CO * TAPS + i] = P.bias ? P.bias[i] : 0.f;
-    for (int i = threadIdx.x; i < 2 * CO; i += 256) bstat[i] = 0.f;
+    for (int i = threadIdx.x; i < CO; i += 256) { ws[CO * TAPS + i] = P.bias ? P.bias[i] : 0.f; ws[CO * TAPS + CO + i] = (P.stats && P.stats_shift) ? P.stats_shift[i] : 0.f; }
     __syncthreads();
     const long npix = (long)P.N * P.D * P.H * P.W;
     float ssum[CO], ssq[CO];
@@ -47,21 +53,24 @@ __global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const chap_conv_c1_par
             float a = ws[CO * TAPS + c];
 #pragma unroll
             for (int t = 0; t < TAPS; ++t) a = fmaf(in[t], ws[c * TAPS + t], a);
-            acc[c] = a; ssum[c] += a; ssq[c] += a * a;
+            acc[c] = a;
+            const float as = a - ws[CO * TAPS + CO + c];        // shifted moments (chap_hip.h, "stats")
+            ssum[c] += as; ssq[c] += as * as;
         }
         T* o = (T*)P.out + pix * CO;
 #pragma unroll
         for (int c = 0; c < CO; c += 8) st8(o + c, acc + c);
     }
-    if (P.stats) {
+    if (P.stats) {          // this block's partial slot: fixed-order wave butterfly, the four waves summed in a fixed order
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
             const float s = wave_sum(ssum[c]), q = wave_sum(ssq[c]);
-            if ((threadIdx.x & 63) == 0) { atomicAdd(&bstat[c], s); atomicAdd(&bstat[CO + c], q); }
+            if ((threadIdx.x & 63) == 0) { bstat[threadIdx.x >> 6][c] = s; bstat[threadIdx.x >> 6][CO + c] = q; }
         }
         __syncthreads();
-        const int rep = P.stats_reps > 1 ? blockIdx.x % P.stats_reps : 0;
-        for (int i = threadIdx.x; i < 2 * CO; i += 256) atomicAdd(&P.stats[(long)rep * 2 * CO + i], bstat[i]);
+        if (blockIdx.x == 0 && threadIdx.x == 0) *(int*)P.stats = (int)gridDim.x;
+        for (int i = threadIdx.x; i < 2 * CO; i += 256)
+            P.stats[CHAP_STATS_HDR + (long)blockIdx.x * 2 * CO + i] = (bstat[0][i] + bstat[1][i]) + (bstat[2][i] + bstat[3][i]);
     }
 }
 
@@ -70,7 +79,7 @@ extern "C" int chap_conv_c1_fwd(const chap_conv_c1_params* p, void* stream) {
     CHAP_CHECK_ARG(p->Cout == 16, "chap_conv_c1_fwd: Cout=%d (only 16 built)", p->Cout);
     CHAP_CHECK_ARG(p->dims == 2 || p->dims == 3, "chap_conv_c1_fwd: dims=%d", p->dims);
     const long npix = (long)p->N * p->D * p->H * p->W;
-    dim3 grid((unsigned)(cdiv(npix, 256) < 2048 ? cdiv(npix, 256) : 2048));
+    dim3 grid((unsigned)(cdiv(npix, 256) < CHAP_STATS_MAX_SLOTS ? cdiv(npix, 256) : CHAP_STATS_MAX_SLOTS));   // one statistics slot per block
     hipStream_t s = (hipStream_t)stream;
     const bool d3 = p->dims == 3, bf = p->dtype == CHAP_BF16;
     if (bf && d3) hipLaunchKernelGGL((conv_c1_fwd_kernel<bf16_t, true, 16>), grid, dim3(256), 0, s, *p);
@@ -216,29 +225,43 @@ extern "C" int chap_conv_c1_bwd(const chap_conv_c1_bwd_params* p, void* stream) 
 // =========================================================================================
 // BatchNorm finalize: batch statistics -> (scale, shift) of the lazy activation; running stats
 // follow F.batch_norm(training=True): running = (1-m)*running + m*batch, unbiased variance.
-__global__ void bn_finalize_kernel(const chap_bn_finalize_params P) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && P.num_batches_tracked && P.momentum > 0.f) *P.num_batches_tracked += 1;
+// One wave per channel: lane l sums slots l, l+64, ... (and the sub-lattice rows of a transposed conv) in fp64, then a
+// fixed xor butterfly -- the same order on every run.  mean = c + S/n, var = Q/n - (S/n)^2 with the moments taken about
+// the conv's shift c (no cancellation once c tracks the mean), evaluated in fp64.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const chap_bn_finalize_params P) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= P.C) return;
-    float s = 0.f, q = 0.f;
-    for (int r = 0; r < P.stats_reps; ++r) { s += P.stats[(long)r * 2 * P.C + c]; q += P.stats[(long)r * 2 * P.C + P.C + c]; }
-    const float mean = s / P.count;
-    float var = q / P.count - mean * mean;
-    var = var > 0.f ? var : 0.f;
-    const float invstd = rsqrtf(var + P.eps);
+    const int nslots = *(const int*)P.stats;
+    const int nsub = P.Clog / P.C;
+    const float* st = P.stats + CHAP_STATS_HDR;
+    double s = 0.0, q = 0.0;
+    for (int b = lane; b < nslots; b += 64) {
+        const float* row = st + (long)b * 2 * P.Clog;
+        for (int k = 0; k < nsub; ++k) { s += (double)row[k * P.C + c]; q += (double)row[P.Clog + k * P.C + c]; }
+    }
+    s = wave_sum_f64(s); q = wave_sum_f64(q);
+    if (lane != 0) return;
+    if (c == 0 && P.num_batches_tracked && P.momentum > 0.f) *P.num_batches_tracked += 1;
+    const double cnt = (double)P.count;
+    const double ms = s / cnt;                                   // mean of (x - shift)
+    double var = q / cnt - ms * ms;
+    var = var > 0.0 ? var : 0.0;
+    const float mean = (float)((P.stats_shift ? (double)P.stats_shift[c] : 0.0) + ms);
+    const float invstd = (float)(1.0 / sqrt(var + (double)P.eps));
     const float sc = P.gamma[c] * invstd;
     P.scale[c] = sc;
     P.shift[c] = P.beta[c] - mean * sc;
     if (P.mean) { P.mean[c] = mean; P.invstd[c] = invstd; }
     if (P.momentum > 0.f && P.running_mean) {
-        const float unb = P.count > 1.f ? var * P.count / (P.count - 1.f) : var;
+        const float unb = (float)(cnt > 1.0 ? var * cnt / (cnt - 1.0) : var);
         P.running_mean[c] = (1.f - P.momentum) * P.running_mean[c] + P.momentum * mean;
         P.running_var[c] = (1.f - P.momentum) * P.running_var[c] + P.momentum * unb;
     }
 }
 extern "C" int chap_bn_finalize(const chap_bn_finalize_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->stats && p->gamma && p->beta && p->scale && p->shift && p->C > 0 && p->count > 0, "chap_bn_finalize: bad argument");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(p->C, 64)), dim3(64), 0, (hipStream_t)stream, *p);
+    CHAP_CHECK_ARG(p->Clog >= p->C && p->Clog % p->C == 0, "chap_bn_finalize: Clog=%d must be a multiple of C=%d", p->Clog, p->C);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(p->C, 4)), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_bn_finalize");
     return CHAP_OK;
 }
@@ -492,9 +515,9 @@ extern "C" int chap_upsample2x_bwd(const chap_upsample_bwd_params* p, void* stre
 // =========================================================================================
 // Backward through the lazy activation (+ pooled consumer) and training-mode BatchNorm.
 // Thread = (pixel, 8 channels); a block covers 256/C8 pixels per step, grid-stride; per-channel
-// partial sums are reduced over the block in LDS and flushed with one atomic per channel.
+// partial sums are reduced over the block in a fixed order and stored as this block's partial row
+// (sums layout: [1 + CHAP_ACT_BWD_SLOTS][2][C], row 0 = totals written by act_bwd_sum_kernel).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-constexpr int ACT_BWD_REPS = CHAP_ACT_BWD_REPS;   // sums layout: [REPS][2][C]
 
 template <typename T>
 __device__ __forceinline__ void act_bwd_dz(const chap_act_bwd_params& P, const float sa[8], const float sb[8], int n, long pix, int y, int x, int c8,
@@ -557,7 +580,7 @@ __device__ __forceinline__ void act_bwd_dz(const chap_act_bwd_params& P, const f
 
 template <typename T, bool APPLY>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params P) {
-    extern __shared__ float red[];            // [2][C] block partials (reduce phase)
+    extern __shared__ float red[];            // reduce phase: [4 waves][2][C] partials; apply phase: [2][C] totals
     const int C = P.r.C, C8 = C / 8;
     const long npix = (long)P.N * P.D * P.H * P.W;
     const int c8 = (threadIdx.x % C8) * 8;
@@ -573,19 +596,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
     for (int j = 0; j < 8; ++j) { cB[j] = 0.f; cC[j] = 0.f; cM[j] = -mean[j] * istd[j]; }      // xhat = raw*istd + cM
     if (APPLY) {
         if (P.bn == 1) {                               // training-mode BatchNorm backward
-            // compact the replicas of the reduce phase cooperatively into LDS (2C x REPS loads per block)
-            for (int i = threadIdx.x; i < 2 * C; i += 256) {
-                float t = 0.f;
-                for (int r = 0; r < ACT_BWD_REPS; ++r) t += P.sums[(long)r * 2 * C + i];
-                red[i] = t;
-            }
+            // totals of the reduce phase (row 0, written by act_bwd_sum_kernel together with dgamma / dbeta)
+            for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = P.sums[i];
             __syncthreads();
-            if (blockIdx.x == 0) {                     // BatchNorm parameter gradients, once
-                for (int c = threadIdx.x; c < C; c += 256) {
-                    if (P.dbeta) P.dbeta[c] += red[c];
-                    if (P.dgamma) P.dgamma[c] += red[C + c];
-                }
-            }
             float gm[8], a0[8], a1[8];
             ld8(P.gamma + c8, gm);
 #pragma unroll
@@ -638,10 +651,11 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
         }
     }
     if (!APPLY) {
-        for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+        for (int i = threadIdx.x; i < 4 * 2 * C; i += 256) red[i] = 0.f;
         __syncthreads();
-        // lanes l, l+C8, l+2*C8, ... of a wave hold the same 8 channels: shuffle-reduce them first so that
-        // only C8 lanes per wave touch LDS (256 threads x 16 same-address LDS atomics were ~10 us per block)
+        // lanes l, l+C8, l+2*C8, ... of a wave hold the same 8 channels: shuffle-reduce them (fixed pairing), one row of
+        // partials per wave in LDS, the four rows summed in a fixed order -> this block's partial row.  No atomics.
+        const int wave = threadIdx.x >> 6;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float a = s0[j], b = s1[j];
@@ -650,29 +664,34 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
             else if (C8 == 4) { a = row16_stride_sum<4>(a); b = row16_stride_sum<4>(b); }
             else if (C8 == 8) { a = row16_stride_sum<8>(a); b = row16_stride_sum<8>(b); }
             for (int o = (C8 > 16 ? C8 : 16); o < 64; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-            if ((threadIdx.x & 63) < C8) { atomicAdd(&red[c8 + j], a); atomicAdd(&red[C + c8 + j], b); }
+            if ((threadIdx.x & 63) < C8 && prow < PPB) { red[(wave * 2 + 0) * C + c8 + j] = a; red[(wave * 2 + 1) * C + c8 + j] = b; }
         }
         __syncthreads();
-        float* dst = P.sums + (long)(blockIdx.x % ACT_BWD_REPS) * 2 * C;
-        for (int i = threadIdx.x; i < 2 * C; i += 256) atomicAdd(&dst[i], red[i]);
+        float* dst = P.sums + (long)(1 + blockIdx.x) * 2 * C;
+        for (int i = threadIdx.x; i < 2 * C; i += 256) {
+            const int which = i / C, c = i % C;
+            dst[i] = (red[(0 * 2 + which) * C + c] + red[(1 * 2 + which) * C + c]) + (red[(2 * 2 + which) * C + c] + red[(3 * 2 + which) * C + c]);
+        }
     }
 }
 
-// Sums the replicas of the reduce phase into replica 0 (read by the apply phase) and accumulates the
-// BatchNorm parameter gradients.
-__global__ void act_bwd_param_kernel(float* sums, float* dgamma, float* dbeta, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float a = 0.f, b = 0.f;
-    for (int r = 0; r < ACT_BWD_REPS; ++r) { a += sums[(long)r * 2 * C + c]; b += sums[(long)r * 2 * C + C + c]; }
-    sums[c] = a; sums[C + c] = b;
-    if (dbeta) dbeta[c] += a;
-    if (dgamma) dgamma[c] += b;
+// Fixed-order total of the per-block partial rows (one wave per value, fp64) into row 0, read by the apply phase;
+// accumulates the BatchNorm parameter gradients.
+__global__ __launch_bounds__(256) void act_bwd_sum_kernel(float* sums, int nblocks, float* dgamma, float* dbeta, int C) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= 2 * C) return;
+    double t = 0.0;
+    for (int b = lane; b < nblocks; b += 64) t += (double)sums[(long)(1 + b) * 2 * C + i];
+    t = wave_sum_f64(t);
+    if (lane != 0) return;
+    const float v = (float)t;
+    sums[i] = v;
+    if (i < C) { if (dbeta) dbeta[i] += v; } else if (dgamma) dgamma[i - C] += v;
 }
 
 static int act_bwd_check(const chap_act_bwd_params* p) {
     CHAP_CHECK_ARG(p && p->r.ptr, "chap_act_bwd: null argument");
-    CHAP_CHECK_ARG(p->r.C % 8 == 0 && 256 % (p->r.C / 8) == 0 && p->r.C <= 2048, "chap_act_bwd: C=%d unsupported", p->r.C);
+    CHAP_CHECK_ARG(p->r.C % 8 == 0 && 256 % (p->r.C / 8) == 0 && p->r.C <= 1024, "chap_act_bwd: C=%d unsupported", p->r.C);
     CHAP_CHECK_ARG(p->ng >= 0 && p->ng <= 3, "chap_act_bwd: ng=%d", p->ng);
     CHAP_CHECK_ARG(p->bn >= 0 && p->bn <= 2, "chap_act_bwd: bn=%d", p->bn);
     CHAP_CHECK_ARG(p->bn != 1 || (p->mean && p->invstd && p->gamma && p->sums), "chap_act_bwd: bn=1 needs mean/invstd/gamma/sums");
@@ -685,19 +704,18 @@ static int act_bwd_blocks(const chap_act_bwd_params* p) {
     long b = (npix + ppb - 1) / ppb;
     // 4 blocks per CU: swept on the whole iteration (512 / 1024 / 2048 / 4096 / 8192 blocks -> 7.59 / 7.39 / 7.58 / 8.07 / 8.01 ms per
     // 2D step): more blocks only add atomics and take CUs from the kernels of the other streams
-    return (int)(b < 1024 ? b : 1024);
+    return (int)(b < CHAP_ACT_BWD_SLOTS ? b : CHAP_ACT_BWD_SLOTS);          // one partial row per block
 }
 extern "C" int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream) {
     int r = act_bwd_check(p); if (r) return r;
     CHAP_CHECK_ARG(p->bn && p->mean && p->invstd && p->sums, "chap_act_bwd_reduce: needs bn, mean, invstd, sums");
-    const size_t lds = 2 * p->r.C * sizeof(float);
-    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, false>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL((act_bwd_kernel<float, false>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
+    const size_t lds = 4 * 2 * p->r.C * sizeof(float);
+    const int nb = act_bwd_blocks(p);
+    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, false>), dim3(nb), dim3(256), lds, (hipStream_t)stream, *p);
+    else hipLaunchKernelGGL((act_bwd_kernel<float, false>), dim3(nb), dim3(256), lds, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_act_bwd_reduce");
-    if (p->bn == 2 && (p->dgamma || p->dbeta)) {      // eval-mode affine: parameter gradients only (apply does not need the sums)
-        hipLaunchKernelGGL(act_bwd_param_kernel, dim3(cdiv(p->r.C, 64)), dim3(64), 0, (hipStream_t)stream, p->sums, p->dgamma, p->dbeta, p->r.C);
-        CHAP_LAUNCH_CHECK("chap_act_bwd_reduce(params)");
-    }
+    hipLaunchKernelGGL(act_bwd_sum_kernel, dim3(cdiv(2 * p->r.C, 4)), dim3(256), 0, (hipStream_t)stream, p->sums, nb, p->dgamma, p->dbeta, p->r.C);
+    CHAP_LAUNCH_CHECK("chap_act_bwd_reduce(sum)");
     return CHAP_OK;
 }
 extern "C" int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream) {
@@ -784,7 +802,7 @@ extern "C" int chap_cl_to_planar(const chap_cl_to_planar_params* p, void* stream
 // gradient is not the B operand of chap_wgrad (transposed conv).
 template <typename T>
 __global__ __launch_bounds__(256) void channel_sum_kernel(const chap_chansum_params P) {
-    extern __shared__ float red[];
+    extern __shared__ float red[];             // [4 waves][C]
     const int C = P.r.C, C8 = C / 8;
     const int c8 = (threadIdx.x % C8) * 8, prow = threadIdx.x / C8, PPB = 256 / C8;
     float s[8];
@@ -796,25 +814,37 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const chap_chansum_par
 #pragma unroll
         for (int j = 0; j < 8; ++j) s[j] += v[j];
     }
-    for (int i = threadIdx.x; i < C; i += 256) red[i] = 0.f;
+    for (int i = threadIdx.x; i < 4 * C; i += 256) red[i] = 0.f;
     __syncthreads();
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float a = s[j];
         for (int o = C8; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
-        if ((threadIdx.x & 63) < C8) atomicAdd(&red[c8 + j], a);
+        if ((threadIdx.x & 63) < C8) red[wave * C + c8 + j] = a;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) atomicAdd(&P.out[i], red[i]);
+    for (int i = threadIdx.x; i < C; i += 256) P.ws[(long)blockIdx.x * C + i] = (red[i] + red[C + i]) + (red[2 * C + i] + red[3 * C + i]);
+}
+// out[c] += fixed-order total of the block partials (one wave per channel, fp64)
+__global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* ws, int nblocks, int C, float* out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double t = 0.0;
+    for (int b = lane; b < nblocks; b += 64) t += (double)ws[(long)b * C + c];
+    t = wave_sum_f64(t);
+    if (lane == 0) out[c] += (float)t;
 }
 extern "C" int chap_channel_sum(const chap_chansum_params* p, void* stream) {
-    CHAP_CHECK_ARG(p && p->r.ptr && p->out && p->r.C % 8 == 0 && 256 % (p->r.C / 8) == 0, "chap_channel_sum: bad argument");
+    CHAP_CHECK_ARG(p && p->r.ptr && p->out && p->ws && p->r.C % 8 == 0 && 256 % (p->r.C / 8) == 0 && p->r.C <= 512, "chap_channel_sum: bad argument");
     const int ppb = 256 / (p->r.C / 8);
     long b = (p->npix + ppb - 1) / ppb;
-    const int nb = (int)(b < 512 ? b : 512);
-    const size_t lds = p->r.C * sizeof(float);
+    const int nb = (int)(b < CHAP_CHANSUM_SLOTS ? b : CHAP_CHANSUM_SLOTS);
+    const size_t lds = 4 * p->r.C * sizeof(float);
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(nb), dim3(256), lds, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nb), dim3(256), lds, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_channel_sum");
+    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(p->r.C, 4)), dim3(256), 0, (hipStream_t)stream, (const float*)p->ws, nb, p->r.C, p->out);
+    CHAP_LAUNCH_CHECK("chap_channel_sum(final)");
     return CHAP_OK;
 }

@@ -19,7 +19,6 @@ from .ops import Lazy
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
-STATS_REPS = 8          # replicas of the BN statistics accumulators (spreads float atomics)
 
 
 class Op:
@@ -171,10 +170,22 @@ class Executor:
         S.train, S.x = train, x
         vals, vdims = S.vals, S.dims
         vdims[prog.in_name] = (D, H, W)
-        # one zeroed fp32 arena for all BN statistics / affines of this pass
+        # one fp32 arena for all BN statistics (per-block partial slots: nothing to zero) / affines of this pass
+        def clog(op):       # logical output channels of the conv = floats per statistics slot row
+            return op.cout * (2 ** dims) if op.kind == "deconv" else op.cout
         nbn = sum(op.cout for op in prog.ops if op.bn or op.inorm)
-        arena = torch.zeros(nbn * (2 * STATS_REPS + 4), dtype=torch.float32, device=dev)
+        nstat = sum(ops.stats_size(clog(op)) for op in prog.ops if (op.bn and train) or op.inorm)
+        arena = torch.empty(nstat + nbn * 5, dtype=torch.float32, device=dev)
         apos = 0
+        # shift of the statistics' moments (sum(x - c), sum((x - c)^2)): a pass-private snapshot of the running means, so
+        # that the conv and its finalize see the same c whatever another stream's pass does to the running statistics
+        rm_flat, rm_off = self.m._running_mean_flat() if train else (None, None)
+        shift_snap = None
+        if rm_flat is not None:
+            shift_snap = self.m._shift_hold                   # the iteration's snapshot (ChapNet.hold_stat_shift), if one is held
+            if shift_snap is None:
+                shift_snap = arena[nstat + nbn * 4:nstat + nbn * 4 + rm_flat.numel()]
+                shift_snap.copy_(rm_flat)
 
         def take(n):
             nonlocal apos
@@ -210,7 +221,11 @@ class Executor:
                 V[op.out], vdims[op.out] = Lazy(out), (od, 2 * h, 2 * w)
                 return
             # ---- convolutions
-            stats = take(STATS_REPS * 2 * op.cout) if ((op.bn and train) or op.inorm) else None
+            stats = take(ops.stats_size(clog(op))) if ((op.bn and train) or op.inorm) else None
+            sshift = None
+            if stats is not None and op.bn and shift_snap is not None:
+                o = rm_off[op.bn]
+                sshift = shift_snap[o:o + op.cout]
             bias = sd[op.b] if op.b else None
             if k == "c1":
                 gd = (D, H, W)
@@ -221,9 +236,9 @@ class Executor:
                     S.xpad = xpad
                     wp = self._pack(op, L.PACK_CONV_FWD, dtype, sd)
                     ops.conv_fwd([Lazy(xpad)], wp, bias, op.cout, out, grid=(n,) + gd, in_dims=gd, ksize=3, stride=1, dims=dims,
-                                 stats=stats, stats_reps=STATS_REPS)
+                                 stats=stats, stats_shift=sshift)
                 else:
-                    ops.conv_c1_fwd(x.view(n, D, H, W), sd[op.w], bias, out, dims=dims, stats=stats, stats_reps=STATS_REPS)
+                    ops.conv_c1_fwd(x.view(n, D, H, W), sd[op.w], bias, out, dims=dims, stats=stats, stats_shift=sshift)
             else:
                 srcs = [V[s] for s in op.srcs]
                 sd_, sh_, sw_ = vdims[op.srcs[0]]
@@ -246,19 +261,19 @@ class Executor:
                     od = (2 * gd[0] if dims == 3 else gd[0], 2 * gd[1], 2 * gd[2])
                     out = torch.empty((n,) + od + (op.cout,), dtype=dtype, device=dev)
                     ops.conv_fwd(srcs, wp, bias, (2 ** dims) * op.cout, out, grid=(n,) + gd, in_dims=ind, ksize=1, stride=1, dims=dims,
-                                 combine=op.combine, out_mode=1, out_cn=op.cout, stats=stats, stats_reps=STATS_REPS)
+                                 combine=op.combine, out_mode=1, out_cn=op.cout, stats=stats, stats_shift=sshift)
                     gd = od
                 else:
                     out = torch.empty((n,) + gd + (op.cout,), dtype=dtype, device=dev)
                     ops.conv_fwd(srcs, wp, bias, op.cout, out, grid=(n,) + gd, in_dims=ind, ksize=ks, stride=st, dims=dims,
-                                 combine=op.combine, stats=stats, stats_reps=STATS_REPS)
+                                 combine=op.combine, stats=stats, stats_shift=sshift)
             vdims[op.out] = gd
             if op.inorm:            # InstanceNorm3d (affine=False) + ReLU: statistics of this single sample
                 scale, shift = take(op.cout), take(op.cout)
                 if op.cout not in self._ident:
                     self._ident[op.cout] = (torch.ones(op.cout, device=dev), torch.zeros(op.cout, device=dev))
                 one, zero = self._ident[op.cout]
-                ops.bn_finalize(stats, STATS_REPS, one, zero, None, None, None, gd[0] * gd[1] * gd[2], BN_EPS, 0.0, scale, shift)
+                ops.bn_finalize(stats, one, zero, None, None, None, gd[0] * gd[1] * gd[2], BN_EPS, 0.0, scale, shift)
                 lz = Lazy(out, scale, shift, True, 0.0)
             elif op.bn:
                 scale, shift = take(op.cout), take(op.cout)
@@ -266,10 +281,11 @@ class Executor:
                     mean, invstd = take(op.cout), take(op.cout)
                     cnt = n * gd[0] * gd[1] * gd[2]
                     upd = update_stats
-                    ops.bn_finalize(stats, STATS_REPS, sd[op.bn + ".weight"], sd[op.bn + ".bias"],
+                    ops.bn_finalize(stats, sd[op.bn + ".weight"], sd[op.bn + ".bias"],
                                     sd[op.bn + ".running_mean"] if upd else None, sd[op.bn + ".running_var"] if upd else None,
                                     sd.get(op.bn + ".num_batches_tracked") if upd else None,
-                                    cnt, BN_EPS, BN_MOMENTUM if upd else 0.0, scale, shift, mean, invstd)
+                                    cnt, BN_EPS, BN_MOMENTUM if upd else 0.0, scale, shift, mean, invstd,
+                                    stats_shift=sshift, clog=clog(op))
                     S.bnstat[op.bn] = (mean, invstd, cnt)
                 else:
                     ops.bn_eval_affine(sd[op.bn + ".weight"], sd[op.bn + ".bias"], sd[op.bn + ".running_mean"], sd[op.bn + ".running_var"],
@@ -349,13 +365,13 @@ class Executor:
         head_g = dict(zip(prog.heads, dlogits))
         dx = None
         nsub = 2 ** dims
-        # one zeroed arena for the BN-backward partial sums of every layer (a single memset per pass)
-        nsum = sum(L.ACT_BWD_REPS * 2 * op.cout for op in prog.ops if op.bn)
-        sums_arena = torch.zeros(nsum, dtype=torch.float32, device=dev)
+        # one arena for the BN-backward partial sums of every layer (per-block partial rows: nothing to zero)
+        nsum = sum(ops.act_bwd_sums_size(op.cout) for op in prog.ops if op.bn)
+        sums_arena = torch.empty(nsum, dtype=torch.float32, device=dev)
         spos = [0]
 
         def take_sums(c):
-            n = L.ACT_BWD_REPS * 2 * c
+            n = ops.act_bwd_sums_size(c)
             t = sums_arena[spos[0]:spos[0] + n]
             spos[0] += n
             return t
@@ -462,22 +478,20 @@ class Executor:
                 if need_wgrad:
                     ops.wgrad(srcs, g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
                               ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid)
-                if self._needs_src_grad(op, need_dx):
-                    wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
-                    dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
-                    ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
-                    scatter(op, srcs, dsrc)
+                wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
+                dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
+                scatter(op, srcs, dsrc)
             elif k == "down":
                 gdd = S.dims[op.out]
                 if need_wgrad:
                     ops.wgrad(srcs, g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
                               ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None)
-                if self._needs_src_grad(op, need_dx):
-                    wp = self._pack(op, L.PACK_DOWN_DGRAD, dtype, sd)
-                    dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
-                    ops.conv_fwd([g], wp, None, nsub * ctot, dsrc, grid=(n,) + gdd, in_dims=gdd, ksize=1, stride=1, dims=dims,
-                                 out_mode=1, out_cn=ctot)
-                    scatter(op, srcs, dsrc)
+                wp = self._pack(op, L.PACK_DOWN_DGRAD, dtype, sd)
+                dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                ops.conv_fwd([g], wp, None, nsub * ctot, dsrc, grid=(n,) + gdd, in_dims=gdd, ksize=1, stride=1, dims=dims,
+                             out_mode=1, out_cn=ctot)
+                scatter(op, srcs, dsrc)
             else:  # deconv: A = fine gradient (kc = co), B = coarse input (kn = ci)
                 fine = S.dims[op.out]
                 if need_wgrad:
@@ -486,11 +500,10 @@ class Executor:
                               ksize=2, stride=2, dims=dims)
                     if op.b:
                         ops.channel_sum(g, gr[op.b])
-                if self._needs_src_grad(op, need_dx):
-                    wp = self._pack(op, L.PACK_DECONV_DGRAD, dtype, sd)
-                    dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
-                    ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=fine, ksize=2, stride=2, dims=dims)
-                    scatter(op, srcs, dsrc)
+                wp = self._pack(op, L.PACK_DECONV_DGRAD, dtype, sd)
+                dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=fine, ksize=2, stride=2, dims=dims)
+                scatter(op, srcs, dsrc)
         # ---- schedule: the decoders' backward passes side by side, then the shared trunk
         cur_stream = torch.cuda.current_stream()
         rev = list(reversed(prog.ops))
@@ -512,9 +525,6 @@ class Executor:
             for op in rev:
                 bwd_op(op)
         return dx
-
-    def _needs_src_grad(self, op, need_dx):
-        return True          # every non-first conv feeds back into earlier layers (BN params / dx)
 
     @staticmethod
     def _scatter(contrib, op, srcs, dsrc):

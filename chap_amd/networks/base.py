@@ -47,6 +47,8 @@ class ChapNet(nn.Module):
         self._exec = Executor(self, program)
         self._flat = None
         self._flat_grad = None
+        self._rm_flat, self._rm_off = None, {}
+        self._shift_buf, self._shift_hold = None, None
         self._manual_version = 0
         self._tensor_cache = None
         self._frozen = False
@@ -80,6 +82,11 @@ class ChapNet(nn.Module):
         for (name, p), off in zip(self._param_list(), self._offsets):
             if p.data_ptr() != base + 4 * off:
                 return False
+        if self._rm_flat is not None:
+            rb = self._rm_flat.data_ptr()
+            for n, o in self._rm_off.items():
+                if self.get_buffer(n + ".running_mean").data_ptr() != rb + 4 * o:
+                    return False
         return True
 
     def _ensure_flat(self):
@@ -101,6 +108,20 @@ class ChapNet(nn.Module):
                 p.data = flat[o:o + p.numel()].view(p.shape)
                 p.grad = None
         self._flat, self._flat_grad, self._offsets = flat, grad, offs
+        # BatchNorm running means in ONE flat buffer too (the modules' buffers become views): a forward pass snapshots
+        # them with a single copy as the shift of its statistics' moments (engine.Executor.forward)
+        rms = [(n, b) for n, b in self.named_buffers() if n.endswith(".running_mean")]
+        self._rm_flat, self._rm_off = None, {}
+        if rms:
+            self._rm_flat = torch.empty(sum(b.numel() for _, b in rms), dtype=torch.float32, device=dev)
+            o = 0
+            with torch.no_grad():
+                for n, b in rms:
+                    v = self._rm_flat[o:o + b.numel()]
+                    v.copy_(b.float())
+                    self.get_submodule(n.rsplit(".", 1)[0])._buffers["running_mean"] = v
+                    self._rm_off[n[:-len(".running_mean")]] = o
+                    o += b.numel()
         self._tensor_cache = None
         self._manual_version += 1
         if self._rng is None or self._rng.seed_dev.device != dev:
@@ -112,6 +133,30 @@ class ChapNet(nn.Module):
             t.update({n: b for n, b in self.named_buffers()})
             self._tensor_cache = t
         return self._tensor_cache
+
+    def _running_mean_flat(self):
+        """(flat fp32 buffer of all BatchNorm running means, {bn prefix: offset}) or (None, None)."""
+        self._ensure_flat()
+        return (self._rm_flat, self._rm_off) if self._rm_flat is not None else (None, None)
+
+    @contextlib.contextmanager
+    def hold_stat_shift(self):
+        """Inside: every forward pass takes the shift of its BatchNorm statistics (the c of sum(x - c), sum((x - c)^2)) from
+        ONE snapshot of the running means made here, on the current stream.  An iteration that runs passes on several
+        streams (ChapStep: pass B beside the VAT branch) needs this to be bitwise reproducible: a pass that snapshots the
+        running means itself would see them before or after another stream's pass has updated them, depending on timing."""
+        self._ensure_flat()
+        if self._rm_flat is None or self._shift_hold is not None:
+            yield self
+            return
+        if self._shift_buf is None or self._shift_buf.shape != self._rm_flat.shape or self._shift_buf.device != self._rm_flat.device:
+            self._shift_buf = torch.empty_like(self._rm_flat)
+        self._shift_buf.copy_(self._rm_flat)
+        self._shift_hold = self._shift_buf
+        try:
+            yield self
+        finally:
+            self._shift_hold = None
 
     def _params_version(self):
         return self._manual_version + sum(p._version for p in self.parameters())
@@ -151,6 +196,23 @@ class ChapNet(nn.Module):
         self._flat_grad = new_flat_grad
         for (name, p), o in zip(self._param_list(), self._offsets):
             p.grad = new_flat_grad[o:o + p.numel()].view(p.shape)
+
+    def backward_saved(self, out, dlogits, grad_buffer):
+        """Run the backward pass of the forward that produced `out` (a logits tensor of this network) directly -- not through
+        torch.autograd -- accumulating the parameter gradients of sum_h <logits_h, dlogits_h> into `grad_buffer` (a flat
+        buffer with this model's layout).  May be called several times on one forward (the saved state is kept until
+        release_saved): the backward pass is linear in dlogits, so the gradients of the parts of a loss can be taken apart
+        (GradSim: labeled vs unlabeled part of the BCP loss)."""
+        ctx = out.grad_fn
+        if ctx is None or getattr(ctx, "S", None) is None:
+            raise RuntimeError("chap_amd: backward_saved needs the output of a forward pass that saved its state")
+        dl = [None if g is None else g.contiguous() for g in dlogits]
+        self._exec.backward(ctx.S, dl, dtype=self.compute_dtype, need_wgrad=True, need_dx=False, grad_buffer=grad_buffer)
+
+    def release_saved(self, out):
+        ctx = out.grad_fn
+        if ctx is not None:
+            ctx.S = None
 
     def _eval_invstd(self, bn, rv):
         return (rv + 1e-5).rsqrt()

@@ -68,7 +68,9 @@ def pack_weights(w, kind, dtype, cin, cout, taps):
 
 def conv_fwd(srcs, wpacked, bias, cout, out, *, grid, in_dims, ksize, stride, dims, combine=0,
              out_ld=None, out_coff=0, out_mode=0, out_cn=0, out_planar=False, out_f32=False,
-             stats=None, stats_reps=1):
+             stats=None, stats_shift=None):
+    """stats: fp32 buffer from `stats_buffer(cout)` (per-block partial slots of the shifted moments, chap_hip.h);
+    stats_shift: fp32 [real channels] or None."""
     p = L.ConvParams()
     for i, s in enumerate(srcs):
         s.fill(p.src[i])
@@ -81,16 +83,44 @@ def conv_fwd(srcs, wpacked, bias, cout, out, *, grid, in_dims, ksize, stride, di
     p.out_ld = out.shape[-1] if out_ld is None else out_ld
     p.out_coff, p.out_mode, p.out_Cn = out_coff, out_mode, out_cn
     p.out_planar, p.out_f32 = int(out_planar), int(out_f32)
-    p.stats, p.stats_reps = _p(stats), stats_reps
+    p.stats, p.stats_shift = _p(stats), _p(stats_shift)
     p.dtype = dt(srcs[0].raw)
     L.call("chap_conv_fwd", p, _stream())
 
 
-def conv_c1_fwd(x, w, bias, out, *, dims, stats=None, stats_reps=1):
+def stats_size(clog):
+    """floats of a BatchNorm-statistics buffer for a conv with `clog` logical output channels."""
+    return L.STATS_HDR + L.STATS_MAX_SLOTS * 2 * clog
+
+
+def stats_buffer(clog, device):
+    return torch.empty(stats_size(clog), dtype=torch.float32, device=device)
+
+
+def stats_totals(stats, clog, creal=None):
+    """Host-side view of a statistics buffer (tests / debugging): fp64 [2, creal] = (sum(v - c), sum((v - c)^2)) over all
+    slots in use, the sub-lattice rows of a transposed conv (clog = nsub * creal) folded.  Synchronises."""
+    n = int(stats[:1].view(torch.int32).item())
+    t = stats[L.STATS_HDR:L.STATS_HDR + n * 2 * clog].view(n, 2, clog).double().sum(0)
+    creal = clog if creal is None else creal
+    return t.view(2, clog // creal, creal).sum(1)
+
+
+def stats_from_moments(s, q):
+    """A one-slot statistics buffer holding the given per-channel moments (tests of chap_bn_finalize)."""
+    c = s.numel()
+    buf = torch.zeros(stats_size(c), dtype=torch.float32, device=s.device)
+    buf[:1].view(torch.int32).fill_(1)
+    buf[L.STATS_HDR:L.STATS_HDR + c] = s
+    buf[L.STATS_HDR + c:L.STATS_HDR + 2 * c] = q
+    return buf
+
+
+def conv_c1_fwd(x, w, bias, out, *, dims, stats=None, stats_shift=None):
     """x: fp32 [N, D, H, W] (C == 1)."""
     p = L.ConvC1Params()
     p.x, p.w, p.bias, p.out = x.data_ptr(), w.data_ptr(), _p(bias), out.data_ptr()
-    p.stats, p.stats_reps = _p(stats), stats_reps
+    p.stats, p.stats_shift = _p(stats), _p(stats_shift)
     p.N, p.D, p.H, p.W = x.shape
     p.dims, p.Cout, p.dtype = dims, out.shape[-1], dt(out)
     L.call("chap_conv_c1_fwd", p, _stream())
@@ -129,10 +159,13 @@ def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine
     L.call("chap_wgrad", p, _stream())
 
 
-def bn_finalize(stats, stats_reps, gamma, beta, running_mean, running_var, nbt, count, eps, momentum,
-                scale, shift, mean=None, invstd=None):
+def bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, count, eps, momentum,
+                scale, shift, mean=None, invstd=None, stats_shift=None, clog=None):
+    """stats: the conv's partial-slot buffer; clog: its logical channel count (C * sub-positions for a transposed conv);
+    stats_shift: the shift the conv was given (read before running_mean is updated)."""
     p = L.BnFinalizeParams()
-    p.stats, p.stats_reps, p.gamma, p.beta = stats.data_ptr(), stats_reps, gamma.data_ptr(), beta.data_ptr()
+    p.stats, p.stats_shift, p.gamma, p.beta = stats.data_ptr(), _p(stats_shift), gamma.data_ptr(), beta.data_ptr()
+    p.Clog = gamma.numel() if clog is None else clog
     p.running_mean, p.running_var, p.num_batches_tracked = _p(running_mean), _p(running_var), _p(nbt)
     p.scale, p.shift, p.mean, p.invstd = scale.data_ptr(), shift.data_ptr(), _p(mean), _p(invstd)
     p.C, p.count, p.eps, p.momentum = gamma.numel(), float(count), eps, momentum
@@ -197,7 +230,7 @@ def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=
         bn_mode = 1 if mean is not None else 0
     need_reduce = bn_mode == 1 or (bn_mode == 2 and (dgamma is not None or dbeta is not None))
     if need_reduce and sums is None:
-        sums = torch.zeros(L.ACT_BWD_REPS * 2 * lazy.C, dtype=torch.float32, device=gout.device)
+        sums = torch.empty(act_bwd_sums_size(lazy.C), dtype=torch.float32, device=gout.device)
     p = _act_bwd_params(lazy, grads, g_pool, pool_idx, mean, invstd, gamma, sums, gout, dgamma, dbeta, count)
     p.bn = bn_mode
     if need_reduce:
@@ -205,10 +238,16 @@ def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=
     L.call("chap_act_bwd_apply", p, _stream())
 
 
+def act_bwd_sums_size(c):
+    """floats of the BN-backward workspace: row 0 = totals, rows 1.. = per-block partials (chap_hip.h)."""
+    return (1 + L.ACT_BWD_SLOTS) * 2 * c
+
+
 def channel_sum(lazy, out):
     p = L.ChanSumParams()
     lazy.fill(p.r)
-    n = lazy.raw.shape[0]
+    ws = torch.empty(L.CHANSUM_SLOTS * lazy.C, dtype=torch.float32, device=out.device)
+    p.ws = ws.data_ptr()
     p.out, p.npix, p.pix_per_sample, p.dtype = out.data_ptr(), lazy.raw[..., 0].numel(), lazy.raw[0, ..., 0].numel(), dt(lazy.raw)
     L.call("chap_channel_sum", p, _stream())
 
@@ -236,7 +275,7 @@ def mix_loss_fwd(logits, target_a, target_b, mask, w_a, w_b, smooth=1e-10, k_dic
     target_b / mask may be None (mask of ones); (k_dice, k_ce) = (0, 0) selects mix_loss's 0.5 / 0.5."""
     N, Cc = logits.shape[0], logits.shape[1]
     p = L.MixLossParams()
-    acc = torch.zeros(2 * (2 + 3 * Cc), dtype=torch.float32, device=logits.device)
+    acc = torch.empty((1 + L.LOSS_SLOTS) * 2 * (2 + 3 * Cc), dtype=torch.float32, device=logits.device)     # row 0 = totals (read by mix_loss_bwd)
     loss = torch.empty(3, dtype=torch.float32, device=logits.device)
     p.logits, p.target_a, p.target_b, p.mask = logits.data_ptr(), target_a.data_ptr(), _p(target_b), _p(mask)
     p.w_a, p.w_b, p.acc, p.loss = w_a, w_b, acc.data_ptr(), loss.data_ptr()
@@ -245,12 +284,13 @@ def mix_loss_fwd(logits, target_a, target_b, mask, w_a, w_b, smooth=1e-10, k_dic
     return loss, acc
 
 
-def mix_loss_bwd(logits, target_a, target_b, mask, w_a, w_b, acc, dlogits, gscale=1.0, accumulate=False, smooth=1e-10, k_dice=0.0, k_ce=0.0):
+def mix_loss_bwd(logits, target_a, target_b, mask, w_a, w_b, acc, dlogits, gscale=1.0, accumulate=False, smooth=1e-10, k_dice=0.0, k_ce=0.0,
+                 gscale_dev=None):
     N, Cc = logits.shape[0], logits.shape[1]
     p = L.MixLossParams()
     p.logits, p.target_a, p.target_b, p.mask = logits.data_ptr(), target_a.data_ptr(), _p(target_b), _p(mask)
     p.w_a, p.w_b, p.acc, p.dlogits = w_a, w_b, acc.data_ptr(), dlogits.data_ptr()
-    p.gscale, p.accumulate = gscale, int(accumulate)
+    p.gscale, p.accumulate, p.gscale_dev = gscale, int(accumulate), _p(gscale_dev)
     p.N, p.C, p.P, p.smooth, p.k_dice, p.k_ce = N, Cc, logits[0, 0].numel(), smooth, k_dice, k_ce
     L.call("chap_mix_loss_bwd", p, _stream())
 
@@ -272,9 +312,18 @@ def pseudo_block(logits1, logits2, want_soft=True):
     return soft1, soft2, arg1, arg2, know
 
 
-def kl_fwd_bwd(logits, targets, loss, dlogits=(None, None), gscale=1.0, gscale_dev=None):
-    """loss (1-elem fp32 tensor) += mean_{n,p} sum_heads KL(target || softmax(logits))."""
+DIST_MODES = {"kl": 0, "dice": 1}
+
+
+def kl_fwd_bwd(logits, targets, loss, dlogits=(None, None), gscale=1.0, gscale_dev=None, mode="kl"):
+    """loss (1-elem fp32 tensor) += the VAT distance between softmax(logits) and targets, summed over the two heads:
+    'kl' = mean_{n,p} KL(target || softmax(logits)), 'dice' = mean_c soft Dice (chap_hip.h, chap_kl_params)."""
     p = L.KlParams()
+    p.mode = DIST_MODES[mode]
+    Cc = logits[0].shape[1]
+    if loss is not None or p.mode == 1:
+        ws = torch.empty((1 + L.LOSS_SLOTS) * 2 * (3 * Cc + 1), dtype=torch.float32, device=logits[0].device)
+        p.ws = ws.data_ptr()
     for h in range(2):
         p.logits[h], p.target[h], p.dlogits[h] = logits[h].data_ptr(), targets[h].data_ptr(), _p(dlogits[h])
     p.loss, p.gscale, p.gscale_dev = _p(loss), gscale, _p(gscale_dev)
@@ -284,7 +333,7 @@ def kl_fwd_bwd(logits, targets, loss, dlogits=(None, None), gscale=1.0, gscale_d
 
 def l2_normalize(x, out, eps=1e-8):
     p = L.L2NormParams()
-    ws = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    ws = torch.empty(x.shape[0] * L.L2NORM_SLOTS, dtype=torch.float32, device=x.device)
     p.in_, p.out, p.N, p.P, p.eps, p.ws = x.data_ptr(), out.data_ptr(), x.shape[0], x[0].numel(), eps, ws.data_ptr()
     L.call("chap_l2_normalize", p, _stream())
 
@@ -397,6 +446,15 @@ def diff_mask(p1, p2, knowledge, scale, topk):
     p.N, p.H, p.W, p.scale, p.topk = N, H, W, scale, topk
     L.call("chap_diff_mask", p, _stream())
     return out
+
+
+def grad_sim(gl, gu, score, ema=0.0):
+    """score[c] = ema * score[c] + (1 - ema) * cos(gl[c, :], gu[c, :]) for the rows (output channels) of a conv kernel's two
+    gradients gl, gu [Cout, Cin, k, k] (contiguous fp32 views)."""
+    p = L.GradSimParams()
+    p.gl, p.gu, p.score = gl.data_ptr(), gu.data_ptr(), score.data_ptr()
+    p.C, p.K, p.ema = gl.shape[0], gl[0].numel(), ema
+    L.call("chap_grad_sim", p, _stream())
 
 
 def sgd_step(param, grad, mom, lr_dev, momentum, weight_decay, grad_scale=1.0, zero_grad=True, grad2=None):

@@ -58,16 +58,18 @@ class FusedSGD:
 
 class VAT2d:
     """adv_loss = VAT2d(xi, epi, num_classes); adv_loss(model, x, soft1, soft2, mask, losstype)
-    (call sites train_ours_2D.py:290,372).  Returns a 1-element device tensor; the gradient of
+    (call sites train_ours_2D.py:290,372); losstype 'kl' or 'dice' (--adv_losstype, :515), `sign=True` = the FGSM-style
+    sign step  r = epi / sqrt(P) * sign(d) * mask.  Returns a 1-element device tensor; the gradient of
     `weight * loss` w.r.t. the parameters is accumulated into the model's gradient buffer here
     (the network node is driven directly with d(loss)/d(logits) from the fused KL kernel)."""
 
     def __init__(self, xi=10.0, epi=6.0, num_classes=4, ip=1, sign=False):
         self.xi, self.epi, self.num_classes, self.ip, self.sign = xi, epi, num_classes, ip, sign
 
-    def __call__(self, model, x, soft1, soft2, mask, losstype="kl", weight_dev=None, inject=None, accumulate_grad=True, grad_buffer=None):
-        if losstype != "kl":
-            raise NotImplementedError("chap_amd VAT2d: adv_losstype=%r (kl built)" % losstype)
+    def __call__(self, model, x, soft1, soft2, mask, losstype="kl", weight_dev=None, inject=None, accumulate_grad=True, grad_buffer=None,
+                 weight=1.0):
+        if losstype not in ops.DIST_MODES:
+            raise ValueError("chap_amd VAT2d: adv_losstype=%r (--adv_losstype {kl,dice}, train_ours_2D.py:515)" % (losstype,))
         inject = inject or {}
         U = soft1.shape[0]
         x = x[-U:].contiguous()                 # "perturb the last U samples" (SURVEY.md section 3.1 note)
@@ -83,7 +85,7 @@ class VAT2d:
             with model.frozen():
                 l1, l2 = model(xh, update_stats=False, drop_masks=inject.get("drop_V%d" % it))
             g1, g2 = torch.empty_like(l1), torch.empty_like(l2)
-            ops.kl_fwd_bwd((l1, l2), (soft1, soft2), None, (g1, g2))
+            ops.kl_fwd_bwd((l1, l2), (soft1, soft2), None, (g1, g2), mode=losstype)
             xh.grad = None
             torch.autograd.backward([l1, l2], [g1, g2])
             ops.l2_normalize(xh.grad, d)
@@ -95,13 +97,51 @@ class VAT2d:
         if accumulate_grad:
             l1, l2 = model(xa, update_stats=False, drop_masks=inject.get("drop_VF"), grad_buffer=grad_buffer)
             g1, g2 = torch.empty_like(l1), torch.empty_like(l2)
-            ops.kl_fwd_bwd((l1, l2), (soft1, soft2), loss, (g1, g2), gscale_dev=weight_dev)
+            ops.kl_fwd_bwd((l1, l2), (soft1, soft2), loss, (g1, g2), gscale=weight, gscale_dev=weight_dev, mode=losstype)
             torch.autograd.backward([l1, l2], [g1, g2])
         else:
             with torch.no_grad():
                 l1, l2 = model(xa, update_stats=False, drop_masks=inject.get("drop_VF"))
-            ops.kl_fwd_bwd((l1, l2), (soft1, soft2), loss)
+            ops.kl_fwd_bwd((l1, l2), (soft1, soft2), loss, mode=losstype)
         return loss
+
+
+class GradSim:
+    """gradsim = grad.GradSim(device, num_classes, dir) (ABSENT upstream; call sites train_ours_2D.py:288,297,360,365): the
+    channel scores of the channel-level perturbation.  Definition of this build (parity unpinned): for each of
+    the five encoder levels, the conv kernel that produces the level's feature (the second conv of its ConvBlock) and, per
+    output channel, the cosine similarity of the gradients of the LABELED part and of the UNLABELED part of the BCP loss
+    (loss_l, loss_u at train_ours_2D.py:352-353) with respect to that kernel -- channels on which the two supervisions agree
+    score high and are kept more often (scores_dropoutV2, FilterDropout.py:116-138).
+
+        init_simsocre() -> [zeros(C_l)]          (:297; all-zero scores = the Dropout2d pair, FilterDropout.py:71-73)
+        get_sim()       -> the current scores     (:360)
+        get_grad_convkernel(grad_l, grad_u, model, optimizer=None, iter_num=0) -> the new scores   (:365)
+
+    Difference to the call site: upstream hands over the two LOSSES (autograd); here the caller hands over the two flat
+    gradient buffers (model layout) that its two backward passes filled."""
+
+    KEYS_2D = ["encoder.in_conv.conv_conv.4.weight"] + ["encoder.down%d.maxpool_conv.1.conv_conv.4.weight" % i for i in range(1, 5)]
+
+    def __init__(self, device, num_classes=4, dir=None, ema=0.0):
+        self.device, self.num_classes, self.dir, self.ema = device, num_classes, dir, ema
+        self.scores = None
+
+    def init_simsocre(self, model=None):
+        chans = (16, 32, 64, 128, 256) if model is None else [dict(model.named_parameters())[k].shape[0] for k in self.KEYS_2D]
+        self.scores = [torch.zeros(c, dtype=torch.float32, device=self.device) for c in chans]
+        return self.scores
+
+    def get_sim(self):
+        if self.scores is None:
+            self.init_simsocre()
+        return self.scores
+
+    def get_grad_convkernel(self, grad_l, grad_u, model, optimizer=None, iter_num=0):
+        vl, vu = model.grad_views_of(grad_l), model.grad_views_of(grad_u)
+        for sc, k in zip(self.get_sim(), self.KEYS_2D):
+            ops.grad_sim(vl[k], vu[k], sc, self.ema)
+        return self.scores
 
 
 class ChapStep:
@@ -134,8 +174,16 @@ class ChapStep:
         self.world_size = world_size
         self.grad_sync = None                   # parallel.DataParallelSync (world_size > 1)
         self._graph = None
-        self.sim_score = None                   # --dropout: per-level channel scores [C_l] (gradsim.get_sim(), absent upstream);
-                                                # None / all-zero = the Dropout2d pair (FilterDropout.py:71-73)
+        # --dropout: per-level channel scores [C_l] = gradsim.get_sim() (train_ours_2D.py:360), refreshed every iteration by
+        # gradsim.get_grad_convkernel (:365); all-zero (the initial value) = the Dropout2d pair (FilterDropout.py:71-73).
+        # `sim_score` (or inject['sim_score']) overrides them.
+        self.sim_score = None
+        self.gradsim = None
+        if a["dropout"] and self.dims == 2:
+            self.gradsim = GradSim(dev, a["num_classes"])
+            self.gradsim.init_simsocre(model)
+            n_ = model.flat_buffers()[1].numel()
+            self._grad_lu = torch.zeros(2 * n_, dtype=torch.float32, device=dev)      # gradients of loss_l | loss_u (pass B)
         # second gradient bucket: the VAT branch accumulates here, so it can run on its own stream beside the
         # BCP branch (and, data-parallel, its all-reduce overlaps); the fused SGD sums both buckets
         n = model.flat_buffers()[1].numel()
@@ -188,7 +236,8 @@ class ChapStep:
         return {"model": {k: v.detach().clone() for k, v in self.model.state_dict().items()},
                 "momentum": self.opt.mom.detach().clone(), "iter_num": int(self.iter_num),
                 "lr": float(self.opt.param_groups[0]["lr"]), "numpy_rng": np.random.get_state(),
-                "rng": {"base": rng.base, "count": rng.count, "seed_dev": int(rng.seed_dev.item())}}
+                "rng": {"base": rng.base, "count": rng.count, "seed_dev": int(rng.seed_dev.item())},
+                "gradsim": None if self.gradsim is None else [sc.detach().clone() for sc in self.gradsim.get_sim()]}
 
     def load_state_dict(self, st):
         self.model.load_state_dict(st["model"], strict=True)
@@ -199,6 +248,9 @@ class ChapStep:
         rng = self.model._rng
         rng.base, rng.count = int(st["rng"]["base"]), int(st["rng"]["count"])
         rng.seed_dev.fill_(int(st["rng"]["seed_dev"]))
+        if self.gradsim is not None and st.get("gradsim") is not None:
+            for dst, src in zip(self.gradsim.get_sim(), st["gradsim"]):
+                dst.copy_(src)
         self.grad_both.zero_()
         return self
 
@@ -212,6 +264,10 @@ class ChapStep:
         self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad2)
 
     def device_step(self, volume_batch, label_batch, inject=None, update=True):
+        with self.model.hold_stat_shift():          # one snapshot of the running means for all passes of the iteration (determinism)
+            return self._device_step(volume_batch, label_batch, inject, update)
+
+    def _device_step(self, volume_batch, label_batch, inject=None, update=True):
         a, model = self.args, self.model
         inject = inject or {}
         nc = a["num_classes"]
@@ -264,12 +320,36 @@ class ChapStep:
                 (out_mix2[:lsub], d2[:lsub], lab_b, plab_b1, False),     # mix_loss4: out_l2
             )
             losses = []
-            for lg, dl, img_l, patch_l, unlab in terms:
+            split = self.gradsim is not None and inject.get("sim_score") is None and self.sim_score is None
+            if split:       # loss_l / loss_u (:352-353) are taken apart: d*_u holds the unlabeled-supervised parts' gradient
+                e1, e2 = torch.empty_like(out_mix1), torch.empty_like(out_mix2)
+                eterms = (e1[lsub:], e2[lsub:], e1[:lsub], e2[:lsub])
+            for ti, (lg, dl, img_l, patch_l, unlab) in enumerate(terms):
                 iw, pw = (0.5, 1.0) if unlab else (1.0, 0.5)            # l_weight=1.0, u_weight=0.5 (:198-203)
                 loss3, acc = ops.mix_loss_fwd(lg, img_l, patch_l, loss_mask, iw, pw)
-                ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, iw, pw, acc, dl)
+                if split:   # (loss_image, loss_patch) = (loss_u_out, loss_l_in) for the unlabeled rows, (loss_l_out, loss_u_in) for the labeled ones (:345-349)
+                    wl, wu = ((0.0, pw), (iw, 0.0)) if unlab else ((iw, 0.0), (0.0, pw))
+                    ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, wl[0], wl[1], acc, dl)
+                    ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, wu[0], wu[1], acc, eterms[ti])
+                else:
+                    ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, iw, pw, acc, dl)
                 losses.append(loss3)
-            torch.autograd.backward([out_mix1, out_mix2], [d1, d2])
+            if not split:
+                torch.autograd.backward([out_mix1, out_mix2], [d1, d2])
+                return losses
+            # two backward passes over the saved forward (linear in dlogits): gradients of loss_l and of loss_u into their own
+            # buffers -> the channel scores of the NEXT iteration (gradsim.get_grad_convkernel, :365); their sum is the BCP
+            # gradient the single pass would have produced
+            n_ = self._grad_lu.numel() // 2
+            g_l, g_u = self._grad_lu[:n_], self._grad_lu[n_:]
+            self._grad_lu.zero_()
+            model.backward_saved(out_mix1, [d1, d2], g_l)
+            model.backward_saved(out_mix1, [e1, e2], g_u)
+            model.release_saved(out_mix1)
+            self._new_scores_from = (g_l, g_u)
+            b0 = self.grad_both[:n_]
+            ops.perturb(b0, g_l, b0, 1.0)
+            ops.perturb(b0, g_u, b0, 1.0)
             return losses
 
         # ---- the VAT branch (:368-375) depends only on pass A: it and pass B run side by side on two streams and
@@ -307,15 +387,17 @@ class ChapStep:
         consistency weight like the VAT term (:378).  Upstream compares the 1.5 U logits with U labels (a shape error) and
         reads the scores from the absent grad.GradSim: here every output row is paired with its own sample's pseudo label,
         cat(pseudo, pseudo[U/2:]), and the scores are `self.sim_score`.  Runs after the VAT branch on the main stream
-        and accumulates into the second gradient bucket; eager only (the weight is applied from the host)."""
-        if capturing:
-            raise NotImplementedError("chap_amd: the dropout (fp_loss) branch runs eagerly (host-side consistency weight)")
+        and accumulates into the second gradient bucket; the consistency weight is read from device memory (`cw_dev`), so
+        the branch is part of a captured iteration like everything else."""
         a, model = self.args, self.model
         if self.dims != 2:
             raise NotImplementedError("chap_amd: the dropout (fp_loss) branch exists for the 2D DualDecoder only, as upstream")
         U = uimg_ab.shape[0]
-        cw = get_current_consistency_weight(self.iter_num // 150, a)
-        o1, o2 = model(uimg_ab, False, True, [0, 1, 2, 3, 4], inject.get("sim_score", self.sim_score), a["comp_drop"],
+        scores = inject.get("sim_score", self.sim_score)
+        produced = scores is None and self.gradsim is not None
+        if produced:
+            scores = self.gradsim.get_sim()                     # of the previous iteration (:360)
+        o1, o2 = model(uimg_ab, False, True, [0, 1, 2, 3, 4], scores, a["comp_drop"],
                        drop_masks=inject.get("drop_FP"), drop_uniforms=inject.get("fp_uniforms"),
                        drop_branches=inject.get("fp_branches"), grad_buffer=self.grad2)
         t1, t2 = torch.cat((pseudo1, pseudo1[U // 2:])), torch.cat((pseudo2, pseudo2[U // 2:]))
@@ -323,10 +405,12 @@ class ChapStep:
         for o, t in ((o1, t2), (o2, t1)):
             l3, acc = ops.mix_loss_fwd(o, t, None, None, 1.0, 0.0, k_dice=0.0, k_ce=1.0)        # mean cross-entropy
             d = torch.empty_like(o)
-            ops.mix_loss_bwd(o, t, None, None, 1.0, 0.0, acc, d, gscale=cw, k_dice=0.0, k_ce=1.0)
+            ops.mix_loss_bwd(o, t, None, None, 1.0, 0.0, acc, d, gscale_dev=self.cw_dev, k_dice=0.0, k_ce=1.0)
             losses.append(l3[0:1])
             ds.append(d)
         torch.autograd.backward([o1, o2], ds)
+        if produced:                                            # :365, after the perturbed pass has read the old scores
+            self.gradsim.get_grad_convkernel(self._new_scores_from[0], self._new_scores_from[1], model, self.opt, self.iter_num)
         return losses
 
     def step(self, volume_batch, label_batch, box_yx=None, inject=None):
@@ -337,23 +421,30 @@ class ChapStep:
         return out
 
     # ------------------------------------------------------------------ HIP graph capture
-    def capture(self, volume_batch, label_batch, warmup=3):
+    def capture(self, volume_batch, label_batch, warmup=3, inject=None, restore=True):
         """Capture device_step() into one HIP graph over static input buffers; afterwards call
-        replay(volume_batch, label_batch)."""
-        if self.args["dropout"]:
-            raise NotImplementedError("chap_amd: the dropout (fp_loss) branch runs eagerly (host-side consistency weight)")
+        replay(volume_batch, label_batch).  The `warmup` eager iterations (allocator, packed-weight tables, lazily set
+        kernel attributes: nothing of that may happen for the first time under capture) run on the given batch; with
+        `restore` (default) parameters, momentum, BatchNorm statistics, iter_num / LR and the RNG state are put back
+        afterwards, so capture() does not train -- without it they count as `warmup` real iterations.  The captured pass
+        itself is not executed: iter_num == number of applied updates at all times.  `inject` (tests): static tensors
+        (dropout masks, VAT noise) the captured iteration reads instead of drawing its own."""
         self._hw = tuple(volume_batch.shape[2:])
         self._static_v = volume_batch.clone()
         self._static_l = label_batch.clone()
+        snap = self.state_dict() if (restore and warmup > 0) else None
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
                 self.prepare()
-                self.device_step(self._static_v, self._static_l)
+                self.device_step(self._static_v, self._static_l, inject)
                 self.finish()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if snap is not None:
+            self.load_state_dict(snap)
+            torch.cuda.synchronize()
         self.model._rng.reset_counter()
         g = torch.cuda.CUDAGraph()
         self.prepare()
@@ -361,16 +452,13 @@ class ChapStep:
         # thread_local: the RCCL watchdog thread polls events while we capture (global mode would abort on that)
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self.model._rng.seed_dev.add_(1)
-            self._static_out = self.device_step(self._static_v, self._static_l, update=not dp)
+            self._static_out = self.device_step(self._static_v, self._static_l, inject, update=not dp)
         self._graph, self._graph_opt = g, None
         if dp:          # data-parallel: [compute graph] -> RCCL all-reduce (eager) -> [optimizer graph]
-            self.grad_sync.start()
-            self.grad_sync.wait()
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode="thread_local"):
                 self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad2)
             self._graph_opt = g2
-        self.finish()
         return g
 
     def replay(self, volume_batch, label_batch, box_yx=None):
@@ -382,6 +470,9 @@ class ChapStep:
             self.grad_sync.start()
             self.grad_sync.wait()
             self._graph_opt.replay()
+        # the optimizer inside the graph changed the weights on the device: the packed copies an EAGER forward
+        # (validation, inference, step()) would otherwise reuse are stale -- the graph itself re-packs on every replay
+        self.model.mark_params_dirty()
         self.finish()
         return self._static_out
 
@@ -394,13 +485,12 @@ class AblationStep(ChapStep):
     SGD + poly LR.  `losses.DiceLoss` is absent upstream: the SSL4MIS definition (1 - (2 sum p t + s)/(sum p^2 + sum t +
     s), s = 1e-5, mean over classes) is used.  The shipped VAT call passes the full-batch soft outputs next to an
     unlabeled-half mask (shape-inconsistent); here, as in the main loop, VAT acts on the unlabeled half.  fp_loss (the
-    `dropout` branch, :209-213) is 0 as upstream.  Eager only (the consistency weight is applied from the host)."""
+    `dropout` branch, :209-213) is 0 as upstream.  The consistency weight lives in device memory: capture()/replay() work."""
 
-    def device_step(self, volume_batch, label_batch, inject=None, update=True):
+    def _device_step(self, volume_batch, label_batch, inject=None, update=True):
         a, model = self.args, self.model
         inject = inject or {}
         lbs = a["labeled_bs"]
-        cw = get_current_consistency_weight(self.iter_num // 150, a)
         out1, out2 = model(volume_batch, drop_masks=inject.get("drop_F"))
         with torch.no_grad():
             soft1, soft2, arg1, arg2, knowledge = ops.pseudo_block(out1[lbs:].contiguous(), out2[lbs:].contiguous())
@@ -413,22 +503,24 @@ class AblationStep(ChapStep):
             l3, acc = ops.mix_loss_fwd(ol, lab, None, None, 1.0, 0.0, smooth=1e-5)            # 0.5*(CE + Dice)
             ops.mix_loss_bwd(ol, lab, None, None, 1.0, 0.0, acc, dl, smooth=1e-5)
             c3, acc2 = ops.mix_loss_fwd(ou, other, None, None, 1.0, 0.0, k_dice=0.0, k_ce=1.0)  # mean CE vs the other head
-            ops.mix_loss_bwd(ou, other, None, None, 1.0, 0.0, acc2, du, gscale=cw, k_dice=0.0, k_ce=1.0)
+            ops.mix_loss_bwd(ou, other, None, None, 1.0, 0.0, acc2, du, gscale_dev=self.cw_dev, k_dice=0.0, k_ce=1.0)
             d[:lbs].copy_(dl); d[lbs:].copy_(du)
             sup.append(l3[0:1]); cps.append(c3[0:1])
         torch.autograd.backward([out1, out2], [d1, d2])
         vat_loss = torch.zeros(1, dtype=torch.float32, device=volume_batch.device)
         if a["adv_noise"]:
             diff_mask = ops.diff_mask(arg1, arg2, knowledge, 4, a["topk1"])
-            self.cw_dev.fill_(cw * a.get("w_adv", 1.0))
             vat_loss = self.adv_loss(model, volume_batch, soft1, soft2, diff_mask, a["adv_losstype"], weight_dev=self.cw_dev,
-                                     inject=inject, grad_buffer=self.grad2)
+                                     inject=inject, grad_buffer=self.grad2, weight=a.get("w_adv", 1.0))
         if update:
             self.exchange_and_update()
-        return {"sup_losses": sup, "cps_losses": cps, "vat_loss": vat_loss, "consistency_weight": cw}
+        return {"sup_losses": sup, "cps_losses": cps, "vat_loss": vat_loss, "consistency_weight": self._cw_host}
 
     def prepare(self, box_yx=None):
-        self._upload_sched([], 0.0)              # no BCP box in this loop; device_step sets the (w_adv-scaled) weight itself
+        self._cw_host = get_current_consistency_weight(self.iter_num // 150, self.args)      # no BCP box in this loop
+        self._upload_sched([], self._cw_host)
 
-    def capture(self, *a, **k):
-        raise NotImplementedError("chap_amd: AblationStep runs eagerly (host-side consistency weight)")
+    def replay(self, volume_batch, label_batch, box_yx=None):
+        out = super().replay(volume_batch, label_batch, box_yx)
+        out["consistency_weight"] = self._cw_host        # the one host-side entry of the (static) output dict
+        return out

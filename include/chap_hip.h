@@ -29,6 +29,12 @@
  *      chap_window_accumulate, chap_window_finalize (the inference callers)
  *   3  chap_sample_channel_sum, chap_channel_drop, chap_fold_perturbed (channel-level perturbation); add-combine
  *      (combine = 1) also for 2D k3 s1 in chap_conv_fwd / chap_wgrad
+ *   4  run-to-run deterministic reductions (the reference sets cudnn.deterministic, train_ours_2D.py:542-547): no float
+ *      atomics anywhere on the training path.  BatchNorm statistics are per-block partial slots (stats layout below) of
+ *      SHIFTED moments sum(x - c), sum((x - c)^2) reduced in fixed order in fp64 by chap_bn_finalize; the BN-backward
+ *      sums, the loss accumulators (chap_mix_loss_*: acc is a workspace of partial rows), chap_kl_fwd_bwd (ws),
+ *      chap_channel_sum (ws), chap_l2_normalize (ws = N * CHAP_L2NORM_SLOTS floats) likewise.  chap_kl_fwd_bwd: `mode`
+ *      (KL or Dice distance).  chap_grad_sim.
  */
 #ifndef CHAP_HIP_H
 #define CHAP_HIP_H
@@ -40,8 +46,13 @@
 extern "C" {
 #endif
 
-#define CHAP_ABI_VERSION 3
-#define CHAP_ACT_BWD_REPS 32   /* replicas of the BN-backward partial sums (spreads float atomics) */
+#define CHAP_ABI_VERSION 4
+#define CHAP_STATS_MAX_SLOTS 1024  /* per-block partial slots of the BatchNorm statistics (one per persistent conv block) */
+#define CHAP_STATS_HDR 4           /* floats in front of the slots; word 0 = number of slots in use (int32)                */
+#define CHAP_ACT_BWD_SLOTS 1024    /* per-block partial slots of the BN-backward sums                                      */
+#define CHAP_LOSS_SLOTS 512        /* per-block partial rows of the loss accumulators                                      */
+#define CHAP_CHANSUM_SLOTS 512
+#define CHAP_L2NORM_SLOTS 256
 
 enum { CHAP_F32 = 0, CHAP_BF16 = 1 };
 enum { CHAP_OK = 0, CHAP_EINVAL = -1, CHAP_EUNSUPPORTED = -2, CHAP_ELAUNCH = -3 };
@@ -70,9 +81,13 @@ typedef struct {
  *                 (3,1) "same", (1,1), (2,2) down-sampling.
  *   out_mode 1    depth-to-space: logical output channel n' = sub*Cn + c is stored at fine pixel
  *                 2*p + sub (transposed conv k2 s2 == 1x1 conv + depth-to-space).
- *   stats         optional per-channel sum / sum-of-squares of the fp32 result (BatchNorm batch
- *                 statistics, F.batch_norm training=True), accumulated with float atomics into
- *                 stats[rep][2][Cout], rep = blockIdx % stats_reps.  Caller zeroes it.
+ *   stats         optional per-channel moments of the fp32 result v (BatchNorm batch statistics, F.batch_norm
+ *                 training=True): every persistent block b writes ITS sums  S = sum(v - c), Q = sum((v - c)^2)  over the
+ *                 pixels it owned to  stats[CHAP_STATS_HDR + (b*2 + {0: S, 1: Q}) * Cout + n]  (plain stores, no
+ *                 atomics, nothing to zero) and block 0 writes the number of blocks into word 0 of the header;
+ *                 c = stats_shift[channel] (any per-channel constant near the mean removes the cancellation in
+ *                 E[x^2] - E[x]^2; NULL = 0).  Buffer: CHAP_STATS_HDR + CHAP_STATS_MAX_SLOTS * 2 * Cout floats.
+ *                 chap_bn_finalize sums the slots in a fixed order: bitwise reproducible for a given launch geometry.
  */
 typedef struct {
     chap_src_t  src[2];
@@ -93,8 +108,8 @@ typedef struct {
     int32_t     out_Cn;        /* channels per sub-position for out_mode 1                        */
     int32_t     out_planar;    /* 1: write fp32 [N][Cout][D][H][W] (logits, NCHW) instead         */
     int32_t     out_f32;       /* 1: out element type is fp32 regardless of dtype                 */
-    float*      stats;         /* [stats_reps][2][Cout] or NULL                                   */
-    int32_t     stats_reps;
+    float*      stats;         /* partial slots (layout above) or NULL                            */
+    const float* stats_shift;  /* [real channels] or NULL: the c of the shifted moments           */
     int32_t     dtype;
 } chap_conv_params;
 
@@ -138,7 +153,7 @@ int chap_pack_multi(const chap_pack_entry* entries_dev, int32_t n, int64_t max_t
  * and weight gradient. */
 typedef struct {
     const float* x;  const float* w;  const float* bias;  /* w: [Cout][1][taps] fp32 */
-    void* out;  float* stats;  int32_t stats_reps;
+    void* out;  float* stats;  const float* stats_shift;   /* as in chap_conv_params */
     int32_t N, D, H, W, dims, Cout, dtype;
 } chap_conv_c1_params;
 int chap_conv_c1_fwd(const chap_conv_c1_params* p, void* stream);
@@ -183,7 +198,9 @@ int    chap_wgrad(const chap_wgrad_params* p, void* stream);
 /* ------------------------------------------------------------------------------------------
  * BatchNorm pieces (nn.BatchNorm2d/3d, unet.py:51,55; vnet.py:21,80,110).                    */
 typedef struct {
-    const float* stats;  int32_t stats_reps;   /* from chap_conv_fwd                               */
+    const float* stats;                        /* partial slots from chap_conv_fwd (header + slots) */
+    const float* stats_shift;                  /* the c the conv was given (NULL = 0); read BEFORE running_mean is updated */
+    int32_t Clog;                              /* floats per slot row = the conv's logical Cout (C * nsub for a transposed conv) */
     const float* gamma;  const float* beta;    /* BN weight / bias                                 */
     float* running_mean; float* running_var;   /* updated in place when momentum > 0               */
     int64_t* num_batches_tracked;              /* +1 when momentum > 0 (may be NULL)               */
@@ -202,8 +219,9 @@ int chap_bn_eval_affine(const chap_bn_eval_params* p, void* stream);
 /* Backward through  a = keep*ks*cm*leaky(scale*r+shift)  [followed by optional 2x2 max-pool
  * routing] and training-mode BatchNorm, for one stored raw tensor r.
  *   phase 1 (reduce): dz = (sum of incoming dact grads) * da/dz;  sums[0][c] = sum dz,
- *                     sums[1][c] = sum dz * rhat              (rhat = (r-mean)*invstd)
- *                     (then the replicas are compacted and dgamma += sums1, dbeta += sums0)
+ *                     sums[1][c] = sum dz * rhat              (rhat = (r-mean)*invstd): per-block partial rows
+ *                     sums[1 + b][2][C] (plain stores), then a fixed-order fp64 sum into row 0 and
+ *                     dgamma += sums1, dbeta += sums0 -- no atomics, bitwise reproducible
  *   phase 2 (apply):  g = gamma*invstd*(dz - sums0/cnt - rhat*sums1/cnt)  -> gout (dtype)
  * Incoming gradients: up to 3 same-grid tensors (ptr, ld, coff) and one half-resolution pooled
  * gradient routed through the saved arg-max index. With bn == 0 (no BatchNorm after the conv)
@@ -213,7 +231,7 @@ typedef struct {
     const void* g_pool; const uint8_t* pool_idx;     /* [N][H/2][W/2][C] each, or NULL           */
     chap_src_t  r;                                   /* the raw tensor + its forward transform    */
     const float* mean; const float* invstd; const float* gamma;
-    float* sums;            /* [CHAP_ACT_BWD_REPS][2][C] workspace, zeroed by the caller            */
+    float* sums;            /* [1 + CHAP_ACT_BWD_SLOTS][2][C] workspace (row 0 = totals); nothing to zero */
     void*  gout;            /* [pixels][C] dtype                                                  */
     float* dgamma; float* dbeta;                     /* accumulated (+=)                          */
     int32_t N, D, H, W;  int32_t bn;  /* 0 none, 1 training-mode BN, 2 fixed affine (eval BN): g = dz*scale */
@@ -247,8 +265,8 @@ int chap_planar_to_cl(const chap_planar_to_cl_params* p, void* stream);  /* fp32
 typedef struct { chap_src_t r; float* out; int32_t N, P; int32_t dtype; } chap_cl_to_planar_params;
 int chap_cl_to_planar(const chap_cl_to_planar_params* p, void* stream);  /* (lazy) [N][P][C] -> fp32 [N][C][P] */
 
-typedef struct { chap_src_t r; float* out; int64_t npix; int64_t pix_per_sample; int32_t dtype; } chap_chansum_params;
-int chap_channel_sum(const chap_chansum_params* p, void* stream);       /* out[c] += sum_pixels a[pixel][c] (fp32, atomics) */
+typedef struct { chap_src_t r; float* out; int64_t npix; int64_t pix_per_sample; int32_t dtype; float* ws; /* CHAP_CHANSUM_SLOTS * C floats */ } chap_chansum_params;
+int chap_channel_sum(const chap_chansum_params* p, void* stream);       /* out[c] += sum_pixels a[pixel][c] (fp32, fixed-order partials) */
 
 /* ------------------------------------------------------------------------------------------
  * Segmentation losses on fp32 planar logits [N][C][P]  (train_ours_2D.py:198-216, 319-325). */
@@ -258,7 +276,8 @@ typedef struct {
     const int64_t* target_b;    /* [N][P] labels under (1-mask)                                    */
     const int64_t* mask;        /* [N][P] in {0,1}                                                 */
     float w_a, w_b;             /* image_weight, patch_weight                                      */
-    float* acc;                 /* [2][1 + 3*C + 1] fp32 workspace, zeroed: ce, per-class i/p2/t2, msum */
+    float* acc;                 /* [1 + CHAP_LOSS_SLOTS][2][1 + 3*C + 1] fp32 workspace: row 0 = totals (ce, per-class i/p2/t2, msum) that
+                                 * chap_mix_loss_fwd leaves for chap_mix_loss_bwd, rows 1.. = per-block partials; nothing to zero */
     float* loss;                /* [3]: loss_a, loss_b, total   (mix_loss return triple)           */
     float* dlogits;             /* [N][C][P] or NULL: d(total*gscale)/dlogits, accumulated (+=) if accumulate */
     float gscale; int32_t accumulate;
@@ -266,6 +285,7 @@ typedef struct {
     /* Generalisation for the second caller (train_ablation_2D.py:171-176,216-217): loss_k = w_k * (k_dice*Dice_k +
      * k_ce*CE_k); k_dice = k_ce = 0 selects mix_loss's 0.5 / 0.5.  mask == NULL: all ones; target_b == NULL: target_a. */
     float k_dice, k_ce;
+    const float* gscale_dev;    /* optional device scalar multiplied into gscale (the consistency weight of a captured iteration) */
 } chap_mix_loss_params;
 int chap_mix_loss_fwd(const chap_mix_loss_params* p, void* stream);
 int chap_mix_loss_bwd(const chap_mix_loss_params* p, void* stream);
@@ -279,11 +299,15 @@ typedef struct {               /* pass-A block: softmax, argmax, cross CE "knowl
 } chap_pseudo_params;
 int chap_pseudo_block(const chap_pseudo_params* p, void* stream);
 
-typedef struct {               /* KL(target || softmax(logits)) summed over both heads, / (N*P)  */
+typedef struct {               /* VAT distance between the two heads' logits and their targets (soft outputs of pass A):  */
     const float* logits[2]; const float* target[2];
     float* loss;  float* dlogits[2];  /* loss += ; dlogits may be NULL                            */
     float gscale; const float* gscale_dev;   /* gradient scale = gscale * (*gscale_dev if given) */
     int32_t N, C, P;
+    int32_t mode;              /* 0 'kl':   sum_heads mean_{n,p} KL(target || softmax(logits))                                */
+                               /* 1 'dice': sum_heads mean_c [1 - (2 sum p t + s) / (sum p^2 + sum t^2 + s)], sums over (n, p), s = 1e-10
+                                *           (--adv_losstype dice, train_ours_2D.py:515); needs ws                             */
+    float* ws;                 /* [1 + CHAP_LOSS_SLOTS][2 heads][3*C + 1] floats: per-block partials (mode 0: one loss value per row) */
 } chap_kl_params;
 int chap_kl_fwd_bwd(const chap_kl_params* p, void* stream);
 
@@ -292,7 +316,7 @@ int chap_kl_fwd_bwd(const chap_kl_params* p, void* stream);
  * DESIGN.md "P1"): per-sample L2 normalise, masked axpy / sign step, counter-based RNG.
  * `seed_dev` (optional, device uint64) is added to `seed` so a captured graph draws new numbers
  * on every replay once the host bumps that word. */
-typedef struct { const float* in; float* out; int32_t N, P; float eps; float* ws; /* N floats */ } chap_l2norm_params;
+typedef struct { const float* in; float* out; int32_t N, P; float eps; float* ws; /* N * CHAP_L2NORM_SLOTS floats */ } chap_l2norm_params;
 int chap_l2_normalize(const chap_l2norm_params* p, void* stream);   /* out[n] = in[n]/(||in[n]||+eps) */
 typedef struct { const float* x; const float* d; const float* mask; float* out; float alpha; int32_t sign; int64_t n; } chap_axpy_params;
 int chap_perturb(const chap_axpy_params* p, void* stream);          /* out = x + alpha*mask*(sign? sgn(d): d) */
@@ -384,6 +408,15 @@ int chap_channel_drop(const chap_channel_drop_params* p, void* stream);
  * w.r.t. feat: out[n] = g[n], and for the unlabeled rows out[B-U+u] += mul[B+u][c] * g[B+u] (mul NULL: plain sum).     */
 typedef struct { const void* g; const float* mul; void* out; int32_t B, U, C, ld, coff; int64_t pix_per_sample; int32_t dtype; } chap_fold_params;
 int chap_fold_perturbed(const chap_fold_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * grad.GradSim (ABSENT from the reference; call sites train_ours_2D.py:288,297,360,365; DESIGN.md "N1"): per OUTPUT
+ * channel c of a conv kernel, the cosine similarity of the labeled-loss and the unlabeled-loss gradients
+ *     sim[c] = <gl[c,:], gu[c,:]> / (||gl[c,:]|| * ||gu[c,:]|| + 1e-12),   rows of K = Cin * taps contiguous floats
+ * (checkpoint layout [Cout][Cin][k][k]); score[c] = ema * score[c] + (1 - ema) * sim[c] (ema = 0: the last iteration's
+ * similarity).  One wave per channel, fixed-order fp64 reduction. */
+typedef struct { const float* gl; const float* gu; float* score; int32_t C, K; float ema; } chap_gradsim_params;
+int chap_grad_sim(const chap_gradsim_params* p, void* stream);
 
 /* Bandwidth calibration helper (tools/membw.py): grid-stride float4 copy with `blocks` blocks of 256. */
 int chap_debug_copy(const void* src, void* dst, int64_t bytes, int32_t blocks, void* stream);

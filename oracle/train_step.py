@@ -11,7 +11,7 @@ cannot be imported -- absent in-repo modules):
     SGD + poly LR            train_ours_2D.py:278, 381-389
 ABSENT from the reference ("parity unpinned"; defined by this build):
     dice_loss_bcp   (losses.DiceLoss_bcp)   masked multi-class Dice, smooth 1e-10
-    vat2d           (losses.VAT2d)          VAT power iteration on the unlabeled half
+    vat2d           (losses.VAT2d)          VAT power iteration on the unlabeled half; distance 'kl' or 'dice' (--adv_losstype)
     create_mask_v1  (patch.create_maskV1)   disagreement OR top-k of the 4x-pooled knowledge map
     sigmoid_rampup  (ramps.sigmoid_rampup)  exp(-5 (1 - t)^2)
 """
@@ -140,13 +140,30 @@ def kl_two_heads(logits, targets):
     return tot
 
 
-def vat2d(model_fn, x, soft1, soft2, mask, d0, xi=10.0, eps=6.0, k=1, sign=False):
+def dice_two_heads(logits, targets, smooth=1e-10):
+    """adv_losstype='dice' (--adv_losstype, train_ours_2D.py:515; losses.VAT2d is ABSENT, PARITY UNPINNED): the soft Dice
+    of the VAT implementations of this script family (softDiceLoss: per class 1 - (2 sum p t + s)/(sum p^2 + sum t^2 + s)
+    with the sums over batch and pixels, mean over classes), summed over the two heads."""
+    tot = 0.0
+    for lg, t in zip(logits, targets):
+        p = F.softmax(lg, 1)
+        red = [0] + list(range(2, p.dim()))
+        inter, z, y = (p * t).sum(red), (p * p).sum(red), (t * t).sum(red)
+        tot = tot + (1.0 - (2.0 * inter + smooth) / (z + y + smooth)).mean()
+    return tot
+
+
+DISTANCES = {"kl": kl_two_heads, "dice": dice_two_heads}
+
+
+def vat2d(model_fn, x, soft1, soft2, mask, d0, xi=10.0, eps=6.0, k=1, sign=False, losstype="kl"):
     """model_fn(x) -> (logits1, logits2) in train mode WITHOUT running-stat updates.
     d0: initial noise in [-0.5, 0.5) (injected). mask [N,1,...] or None. Returns (loss, r_adv)."""
+    dist_fn = DISTANCES[losstype]
     d = l2_normalize(d0)
     for _ in range(k):
         d = d.detach().requires_grad_(True)
-        dist = kl_two_heads(model_fn(x + xi * d), (soft1, soft2))
+        dist = dist_fn(model_fn(x + xi * d), (soft1, soft2))
         g, = torch.autograd.grad(dist, d)
         d = l2_normalize(g)
     d = d.detach()
@@ -156,7 +173,24 @@ def vat2d(model_fn, x, soft1, soft2, mask, d0, xi=10.0, eps=6.0, k=1, sign=False
         r = eps * d
     if mask is not None:
         r = r * mask
-    return kl_two_heads(model_fn(x + r), (soft1, soft2)), r
+    return dist_fn(model_fn(x + r), (soft1, soft2)), r
+
+
+GRADSIM_KEYS_2D = ["encoder.in_conv.conv_conv.4.weight"] + ["encoder.down%d.maxpool_conv.1.conv_conv.4.weight" % i for i in range(1, 5)]
+
+
+def grad_sim_scores(loss_l, loss_u, sd, keys=GRADSIM_KEYS_2D):
+    """grad.GradSim.get_grad_convkernel (ABSENT upstream, call site train_ours_2D.py:365; PARITY UNPINNED -- the build's
+    definition): per output channel of the conv kernel that produces each encoder feature, the cosine similarity
+    of d loss_l / dW and d loss_u / dW."""
+    ws = [sd[k] for k in keys]
+    gl = torch.autograd.grad(loss_l, ws, retain_graph=True)
+    gu = torch.autograd.grad(loss_u, ws, retain_graph=True)
+    out = []
+    for a, b in zip(gl, gu):
+        a, b = a.reshape(a.shape[0], -1).double(), b.reshape(b.shape[0], -1).double()
+        out.append(((a * b).sum(1) / (a.norm(dim=1) * b.norm(dim=1) + 1e-12)).float())
+    return out
 
 
 def sgd_step(params, grads, moms, lr, momentum=0.9, weight_decay=1e-4):
@@ -171,7 +205,7 @@ def sgd_step(params, grads, moms, lr, momentum=0.9, weight_decay=1e-4):
 # --------------------------------------------------------------------------- the whole iteration
 ORACLE_ARGS = dict(base_lr=0.01, labeled_bs=12, max_iterations=30000, num_classes=4, consistency=1.0,
                    consistency_rampup=50.0, noise_mag=10.0, epi=6.0, topk1=0.1, adv_noise=True, vat_iters=1,
-                   vat_sign=False, nms=1, momentum=0.9, weight_decay=1e-4)
+                   vat_sign=False, adv_losstype="kl", nms=1, momentum=0.9, weight_decay=1e-4)
 
 
 def iteration(sd, moms, volume_batch, label_batch, box_yx, iter_num, lr, args=None, inject=None, net=None):
@@ -223,7 +257,7 @@ def iteration(sd, moms, volume_batch, label_batch, box_yx, iter_num, lr, args=No
             return net(sd, xx, train=True, drop=inject.get(key), update_stats=False)
 
         d0 = inject["d0"] if inject.get("d0") is not None else torch.rand(uimg_ab.shape, device=uimg_ab.device) - 0.5
-        vat_loss, _ = vat2d(model_fn, uimg_ab, soft1, soft2, diff, d0, a["noise_mag"], a["epi"], a["vat_iters"], a["vat_sign"])
+        vat_loss, _ = vat2d(model_fn, uimg_ab, soft1, soft2, diff, d0, a["noise_mag"], a["epi"], a["vat_iters"], a["vat_sign"], a["adv_losstype"])
     else:
         vat_loss = torch.zeros((), device=volume_batch.device)
     fp_loss = torch.zeros((), device=volume_batch.device)
@@ -237,12 +271,22 @@ def iteration(sd, moms, volume_batch, label_batch, box_yx, iter_num, lr, args=No
         U = uimg_ab.shape[0]
         ctx = nets.Ctx(True, inject.get("drop_FP"), True)
         feats = nets.encoder_2d(sd, uimg_ab, ctx)
-        f1, f2 = ofd.perform_dropout(feats, [0, 1, 2, 3, 4], inject.get("sim_score"), a.get("comp_drop", False),
+        scores_in = inject.get("sim_score")
+        if scores_in is None and inject.get("gradsim") is not None:          # gradsim.get_sim() (:360): the previous iteration's scores
+            scores_in = [sc.clone() for sc in inject["gradsim"]]
+        f1, f2 = ofd.perform_dropout(feats, [0, 1, 2, 3, 4], scores_in, a.get("comp_drop", False),
                                      inject["fp_uniforms"], inject.get("fp_branches"))
         o1fp, o2fp = nets.decoder_2d(sd, "decoder1", f1, ctx), nets.decoder_2d(sd, "decoder2", f2, ctx)
         t1, t2 = torch.cat((arg1, arg1[U // 2:])), torch.cat((arg2, arg2[U // 2:]))
         fp_terms = (F.cross_entropy(o1fp, t2), F.cross_entropy(o2fp, t1))
         fp_loss = fp_terms[0] + fp_terms[1]
+        if inject.get("sim_score") is None and inject.get("gradsim") is not None:
+            # gradsim.get_grad_convkernel(loss_l, loss_u, ...) (:352-353,365): mix_loss returns (loss_image, loss_patch, total) =
+            # (loss_u_out, loss_l_in, .) for the unlabeled rows and (loss_l_out, loss_u_in, .) for the labeled ones (:345-349)
+            loss_l = m1[1] + m2[1] + m3[0] + m4[0]
+            loss_u = m1[0] + m2[0] + m3[1] + m4[1]
+            for dst, new in zip(inject["gradsim"], grad_sim_scores(loss_l, loss_u, sd)):
+                dst.copy_(new)
     loss = bcp_loss + cw * (fp_loss + vat_loss)
     names = [k for k, v in sd.items() if v.is_floating_point() and v.requires_grad]
     grads = torch.autograd.grad(loss, [sd[k] for k in names], allow_unused=True)
@@ -301,7 +345,8 @@ def ablation_iteration(sd, moms, volume_batch, label_batch, iter_num, lr, args=N
 
         x_u = volume_batch[lbs:]
         d0 = inject["d0"] if inject.get("d0") is not None else torch.rand(x_u.shape) - 0.5
-        vat_loss, _ = vat2d(model_fn, x_u, soft1[lbs:].detach(), soft2[lbs:].detach(), diff, d0, a["noise_mag"], a["epi"], a["vat_iters"], a["vat_sign"])
+        vat_loss, _ = vat2d(model_fn, x_u, soft1[lbs:].detach(), soft2[lbs:].detach(), diff, d0, a["noise_mag"], a["epi"], a["vat_iters"], a["vat_sign"],
+                            a["adv_losstype"])
     else:
         vat_loss = torch.zeros(())
     fp_loss = torch.zeros(())

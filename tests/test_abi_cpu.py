@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 35
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.chap_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.chap_abi_version() == _lib.ABI_VERSION == 4
     # every entry point bound in the ctypes tables is declared in the header and vice versa
     bound = set(_lib._SIGS) | set(_lib._SIZE_FNS) | {"chap_last_error", "chap_abi_version", "chap_debug_copy", "chap_pack_describe", "chap_pack_multi"}
     assert bound == set(names), (bound ^ set(names))
@@ -136,3 +136,46 @@ def test_graft_entry_build():
     """The driver's build check: compiles (no-op when up to date), loads the library and checks the ABI version."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_networks_shim_resolves_the_reference_imports():
+    """`PYTHONPATH=chap_amd/shim`: the import lines of the reference's scripts (code/test_2D_fully.py:14,
+    code/train_ours_2D.py:22, code/test_LA.py:4, code/test_3D.py:8) resolve to the chap_amd implementations."""
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from networks.net_factory import net_factory\n"
+            "from networks.net_factory_3d import net_factory_3d\n"
+            "from networks.unet_3D import unet_3D\n"
+            "from networks.unet import DualDecoder, UNet\n"
+            "from networks.vnet import VNet\n"
+            "import chap_amd.networks as n\n"
+            "assert net_factory is n.net_factory and net_factory_3d is n.net_factory_3d and unet_3D is n.unet_3D and DualDecoder is n.DualDecoder\n"
+            "import inspect\n"
+            "assert list(inspect.signature(net_factory).parameters) == ['net_type', 'in_chns', 'class_num', 'device', 'args']\n"
+            "assert list(inspect.signature(net_factory_3d).parameters) == ['net_type', 'in_chns', 'class_num', 'mode', 'device', 'args']\n"
+            "from chap_amd.train_ours_2D import train\n"
+            "assert list(inspect.signature(train).parameters) == ['args', 'snapshot_path']\n") % (ROOT, os.path.join(ROOT, "chap_amd", "shim"))
+    subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_oracle_sgd_step_is_torch_optim_sgd():
+    """Pin of H17: the oracle's sgd_step against the reference's actual optimizer, optim.SGD(lr, momentum=0.9,
+    weight_decay=1e-4) (code/train_ours_2D.py:278), over 3 steps with the poly LR applied AFTER each step (:385-389)."""
+    from oracle import train_step as ots
+    g = torch.Generator().manual_seed(0)
+    shapes = [(16, 1, 3, 3), (16,), (32, 16, 3, 3), (7,)]
+    p_ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    p_or = [p.detach().clone() for p in p_ref]
+    moms = [torch.zeros_like(p) for p in p_or]
+    opt = torch.optim.SGD(p_ref, lr=0.01, momentum=0.9, weight_decay=0.0001)
+    lr = 0.01
+    for it in range(3):
+        grads = [torch.randn(s, generator=g) for s in shapes]
+        for p, gr in zip(p_ref, grads):
+            p.grad = gr.clone()
+        opt.step()
+        ots.sgd_step(p_or, grads, moms, lr, 0.9, 1e-4)
+        lr = ots.poly_lr(0.01, it + 1, 30000)
+        for pg in opt.param_groups:
+            pg["lr"] = 0.01 * (1.0 - (it + 1) / 30000) ** 0.9           # train_ours_2D.py:387-389
+        for a, b in zip(p_ref, p_or):
+            assert torch.allclose(a.detach(), b, rtol=2e-6, atol=1e-7), (it, float((a.detach() - b).abs().max()))     # same formula; fused-multiply order differs

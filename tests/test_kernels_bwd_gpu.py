@@ -169,6 +169,16 @@ def test_losses_vs_oracle():
     ops.kl_fwd_bwd((ld, l2.to(DEV)), (t1.to(DEV), t2.to(DEV)), lossd, (g1, g2), gscale=0.7)
     assert relerr(lossd.cpu(), kl.detach().reshape(1)) < 1e-5
     assert relerr(g1, la.grad) < 1e-4 and relerr(g2, lb.grad) < 1e-4
+    # Dice distance of the two heads (--adv_losstype dice) + gradient; loss accumulates into `loss` (+=)
+    la, lb = logits.clone().requires_grad_(True), l2.clone().requires_grad_(True)
+    dd = ots.dice_two_heads((la, lb), (t1, t2)); (dd * 0.7).backward()
+    lossd = torch.full((1,), 0.25, device=DEV)
+    ops.kl_fwd_bwd((ld, l2.to(DEV)), (t1.to(DEV), t2.to(DEV)), lossd, (g1, g2), gscale=0.7, mode="dice")
+    assert relerr(lossd.cpu() - 0.25, dd.detach().reshape(1)) < 1e-5
+    assert relerr(g1, la.grad) < 1e-4 and relerr(g2, lb.grad) < 1e-4
+    # every reduction on the way is fixed-order: bitwise identical on a second run
+    loss_b, acc_b = ops.mix_loss_fwd(ld, ta.to(DEV), tb.to(DEV), lm.long().to(DEV), 0.5, 1.0)
+    assert torch.equal(loss_b.view(torch.int32), loss.view(torch.int32))
 
 
 def test_lcc_diffmask_vat_helpers_sgd():

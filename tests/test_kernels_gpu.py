@@ -57,14 +57,16 @@ def test_conv3x3_2d_plain(dtype, cin, cout, hw):
     xd = cl(x, dtype)
     wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, cin, cout, 9)
     out = torch.empty(N, 1, H, W, cout, device=DEV, dtype=dtype)
-    stats = torch.zeros(2, 2, cout, device=DEV)
+    stats = ops.stats_buffer(cout, DEV)
+    c0 = torch.randn(cout, generator=g)                      # shift of the moments: sum(v - c), sum((v - c)^2)
     ops.conv_fwd([ops.Lazy(xd)], wp, b.to(DEV), cout, out, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2,
-                 stats=stats, stats_reps=2)
+                 stats=stats, stats_shift=c0.to(DEV))
     torch.cuda.synchronize()
     assert relerr(uncl(out).squeeze(2), ref) < TOL[dtype]
-    s = stats.sum(0).cpu()
-    assert relerr(s[0], ref.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
-    assert relerr(s[1], (ref * ref).sum((0, 2, 3))) < 1e-3 + TOL[dtype]
+    s = ops.stats_totals(stats, cout).float().cpu()
+    rc = ref - c0.view(1, -1, 1, 1)
+    assert relerr(s[0], rc.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
+    assert relerr(s[1], (rc * rc).sum((0, 2, 3))) < 1e-3 + TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -188,12 +190,23 @@ def test_conv3d_family(dtype):
     ref = F.conv_transpose3d(x, rq(w, dtype), b, stride=2)
     wp = ops.pack_weights(w.to(DEV), L.PACK_DECONV_FWD, dtype, 64, 32, 8)
     out = torch.empty(N, 6, 10, 12, 32, device=DEV, dtype=dtype)
-    stats = torch.zeros(1, 2, 32, device=DEV)
+    stats = ops.stats_buffer(8 * 32, DEV)
+    c0 = torch.randn(32, generator=g)
     ops.conv_fwd([ops.Lazy(cl(x, dtype))], wp, b.to(DEV), 8 * 32, out, grid=(N, 3, 5, 6), in_dims=(3, 5, 6), ksize=1, stride=1, dims=3,
-                 out_mode=1, out_cn=32, stats=stats)
+                 out_mode=1, out_cn=32, stats=stats, stats_shift=c0.to(DEV))
     assert relerr(uncl(out), ref) < TOL[dtype]
-    assert relerr(stats[0, 0].cpu(), ref.sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
-    assert relerr(stats[0, 1].cpu(), (ref * ref).sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
+    st = ops.stats_totals(stats, 8 * 32, 32).float().cpu()
+    rc = ref - c0.view(1, -1, 1, 1, 1)
+    assert relerr(st[0], rc.sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
+    assert relerr(st[1], (rc * rc).sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
+    # ... and chap_bn_finalize folds the 8 sub-lattice rows: batch statistics of the 32 real channels
+    gamma, beta = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g)
+    scale, shift = torch.empty(32, device=DEV), torch.empty(32, device=DEV)
+    mean, invstd = torch.empty(32, device=DEV), torch.empty(32, device=DEV)
+    ops.bn_finalize(stats, gamma.to(DEV), beta.to(DEV), None, None, None, ref[:, 0].numel(), 1e-5, 0.0, scale, shift, mean, invstd,
+                    stats_shift=c0.to(DEV), clog=8 * 32)
+    assert relerr(mean, ref.mean((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
+    assert relerr(invstd, (ref.var((0, 2, 3, 4), unbiased=False) + 1e-5).rsqrt()) < 1e-3 + TOL[dtype]
     # 1x1x1 head 16 -> 2, planar fp32
     x = rq(torch.randn(N, 16, D, H, W, generator=g), dtype)
     w = torch.randn(2, 16, 1, 1, 1, generator=g) / 4
@@ -219,13 +232,18 @@ def test_first_conv_c1(dtype, dims):
     ref = (F.conv2d if dims == 2 else F.conv3d)(xin, w, b, padding=1)
     xd = x.to(DEV)
     out = torch.empty(*xd.shape, 16, device=DEV, dtype=dtype)
-    stats = torch.zeros(4, 2, 16, device=DEV)
-    ops.conv_c1_fwd(xd, w.to(DEV), b.to(DEV), out, dims=dims, stats=stats, stats_reps=4)
+    stats = ops.stats_buffer(16, DEV)
+    c0 = torch.randn(16, generator=g)
+    ops.conv_c1_fwd(xd, w.to(DEV), b.to(DEV), out, dims=dims, stats=stats, stats_shift=c0.to(DEV))
     got = uncl(out)
     if dims == 2:
         got = got.squeeze(2)
     assert relerr(got, ref) < (1e-5 if dtype == torch.float32 else 1e-2)
-    assert relerr(stats.sum(0)[0].cpu(), ref.sum([0] + list(range(2, ref.dim())))) < 1e-3
+    red = [0] + list(range(2, ref.dim()))
+    rc = ref - c0.view([1, -1] + [1] * (ref.dim() - 2))
+    st = ops.stats_totals(stats, 16).float().cpu()
+    assert relerr(st[0], rc.sum(red)) < 1e-3
+    assert relerr(st[1], (rc * rc).sum(red)) < 1e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -274,14 +292,26 @@ def test_pool_upsample_bnfinalize(dtype):
     rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
     rm_ref, rv_ref = rm.clone(), rv.clone()
     ref = F.batch_norm(y, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
-    stats = torch.stack([y.sum((0, 2, 3)), (y * y).sum((0, 2, 3))]).unsqueeze(0).to(DEV).contiguous()
+    c0 = rm.clone()                                          # moments about the (old) running mean, as the engine does
+    yc = y - c0.view(1, C, 1, 1)
+    stats = ops.stats_from_moments(yc.sum((0, 2, 3)).to(DEV), (yc * yc).sum((0, 2, 3)).to(DEV))
     scale, shift = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     mean, invstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
     rmd, rvd, nbt = rm.to(DEV), rv.to(DEV), torch.zeros((), dtype=torch.long, device=DEV)
-    ops.bn_finalize(stats, 1, gamma.to(DEV), beta.to(DEV), rmd, rvd, nbt, 4 * 36, 1e-5, 0.1, scale, shift, mean, invstd)
+    ops.bn_finalize(stats, gamma.to(DEV), beta.to(DEV), rmd, rvd, nbt, 4 * 36, 1e-5, 0.1, scale, shift, mean, invstd, stats_shift=c0.to(DEV))
     got = y * scale.cpu().view(1, C, 1, 1) + shift.cpu().view(1, C, 1, 1)
     assert relerr(got, ref) < 1e-5
     assert relerr(rmd, rm_ref) < 1e-5 and relerr(rvd, rv_ref) < 1e-5 and int(nbt) == 1
+    # |mean| >> std: E[x^2] - E[x]^2 about 0 loses the variance in fp32, the shifted moments do not (F.batch_norm: Welford)
+    y2 = torch.randn(4, C, 6, 6, generator=g) * 1e-2 + 300.0
+    ref2 = F.batch_norm(y2, None, None, gamma, beta, True, 0.1, 1e-5)
+    c2 = y2.mean((0, 2, 3)) + 0.05                           # a shift NEAR the mean (what a running mean is)
+    yc = (y2 - c2.view(1, C, 1, 1)).to(DEV)                  # fp32 sums on the device, like the conv epilogue
+    stats = ops.stats_from_moments(yc.sum((0, 2, 3)), (yc * yc).sum((0, 2, 3)))
+    ops.bn_finalize(stats, gamma.to(DEV), beta.to(DEV), None, None, None, 4 * 36, 1e-5, 0.0, scale, shift, mean, invstd, stats_shift=c2.to(DEV))
+    got2 = y2 * scale.cpu().view(1, C, 1, 1) + shift.cpu().view(1, C, 1, 1)
+    assert (got2 - ref2).abs().max() < 5e-2 * ref2.abs().max()      # limited by fp32 (y * scale + shift) at |y| = 300, not by the variance
+    assert relerr(invstd, (y2.double().var((0, 2, 3), unbiased=False) + 1e-5).rsqrt().float()) < 1e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -307,11 +337,11 @@ def test_conv3d_bricks_ragged(dtype, shape, c, add2):
     ref = F.conv3d(rq(a, dtype), rq(w, dtype), b, padding=1)
     wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, c, c, 27)
     out = torch.empty(N, D, H, W, c, device=DEV, dtype=dtype)
-    stats = torch.zeros(8, 2, c, device=DEV)
+    stats = ops.stats_buffer(c, DEV)
     ops.conv_fwd(srcs, wp, b.to(DEV), c, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=3,
-                 combine=1 if add2 else 0, stats=stats, stats_reps=8)
+                 combine=1 if add2 else 0, stats=stats)
     assert relerr(uncl(out), ref) < 2 * TOL[dtype]
-    st = stats.sum(0).cpu()
+    st = ops.stats_totals(stats, c).float().cpu()
     assert relerr(st[0], ref.sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
     assert relerr(st[1], (ref * ref).sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
 
@@ -333,11 +363,16 @@ def test_conv3x3_2d_bench_shapes_ragged(dtype, N, hw, cin, cout):
     ref = F.conv2d(rq(a, dtype), rq(w, dtype), b, padding=1)
     wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, cin, cout, 9)
     out = torch.empty(N, 1, H, W, cout, device=DEV, dtype=dtype)
-    stats = torch.zeros(8, 2, cout, device=DEV)
+    stats = ops.stats_buffer(cout, DEV)
     km = keep.permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(DEV, torch.uint8)
     src = ops.Lazy(cl(x, dtype), sc.to(DEV), sh.to(DEV), True, 0.01, keep=km, keep_scale=1.25)
-    ops.conv_fwd([src], wp, b.to(DEV), cout, out, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2, stats=stats, stats_reps=8)
+    ops.conv_fwd([src], wp, b.to(DEV), cout, out, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2, stats=stats)
     assert relerr(uncl(out).squeeze(2), ref) < 2 * TOL[dtype]
-    st = stats.sum(0).cpu()
+    st = ops.stats_totals(stats, cout).float().cpu()
+    # bitwise reproducible: no atomics on the way (a second launch gives the same slots)
+    first = stats.clone()
+    ops.conv_fwd([src], wp, b.to(DEV), cout, out, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2, stats=stats)
+    nslots = int(first[:1].view(torch.int32).item())
+    assert torch.equal(first[:L.STATS_HDR + nslots * 2 * cout].view(torch.int32), stats[:L.STATS_HDR + nslots * 2 * cout].view(torch.int32))
     assert relerr(st[0], ref.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
     assert relerr(st[1], (ref * ref).sum((0, 2, 3))) < 1e-3 + TOL[dtype]

@@ -17,18 +17,18 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
     T *x, *y, *wp; float *sc, *sh, *st;
     hipMalloc(&x, nin * 2); hipMalloc(&y, nout * 2);
     size_t wbytes_all = (size_t)nchunks * STEPS * ntile16 * 64 * 8 * 2;
-    hipMalloc(&wp, wbytes_all); hipMalloc(&sc, Cin * 4); hipMalloc(&sh, Cin * 4); hipMalloc(&st, 8 * 2 * Cout * 4);
+    hipMalloc(&wp, wbytes_all); hipMalloc(&sc, Cin * 4); hipMalloc(&sh, Cin * 4); hipMalloc(&st, (CHAP_STATS_HDR + (size_t)CHAP_STATS_MAX_SLOTS * 2 * Cout) * 4);
     std::vector<T> hx(nin); for (size_t i = 0; i < nin; ++i) hx[i] = 0x3c00 + (rand() & 0x3ff);
     hipMemcpy(x, hx.data(), nin * 2, hipMemcpyHostToDevice);
     std::vector<T> hw(wbytes_all / 2); for (auto& v : hw) v = 0x3800 + (rand() & 0xff);
     hipMemcpy(wp, hw.data(), wbytes_all, hipMemcpyHostToDevice);
     std::vector<float> hs(Cin, 1.01f); hipMemcpy(sc, hs.data(), Cin * 4, hipMemcpyHostToDevice); hipMemcpy(sh, hs.data(), Cin * 4, hipMemcpyHostToDevice);
-    hipMemset(st, 0, 8 * 2 * Cout * 4);
+    
     chap_conv_params P = {};
     P.src[0].ptr = x; P.src[0].C = Cin; P.src[0].ld = Cin; P.src[0].slope = 0.01f; P.src[0].keep_scale = 1.f;
     if (prologue) { P.src[0].scale = sc; P.src[0].shift = sh; P.src[0].act = 1; }
     P.nsrc = 1; P.N = N; P.D = D; P.H = H; P.W = W; P.ID = D; P.IH = H; P.IW = W; P.ksize = KS; P.stride = 1; P.dims = D3 ? 3 : 2;
-    P.wpacked = wp; P.out = y; P.Cout = Cout; P.out_ld = Cout; P.stats = stats ? st : nullptr; P.stats_reps = 8; P.dtype = CHAP_BF16;
+    P.wpacked = wp; P.out = y; P.Cout = Cout; P.out_ld = Cout; P.stats = stats ? st : nullptr; P.stats_shift = nullptr; P.dtype = CHAP_BF16;
     auto kern = conv_fwd_kernel<T, KS, 1, D3, KC, NT, MR, false, WLDS, ZW, true>;
     size_t lds_fixed_only = conv_lds_fixed_bytes<T, KS, 1, D3, KC, MR, ZW>(NT) + 2 * CONV_MAX_AFFINE_C * 4;
     const bool fits = conv_wstaged<T, KS, 1, D3, KC, NT, MR, ZW>();

@@ -20,9 +20,9 @@ def conv_case(N, H, cin, cout, dtype, stats, prologue, ks=3):
     w = torch.randn(cout, cin, ks, ks, device=dev) / 12
     wp = ops.pack_weights(w, L.PACK_CONV_FWD, dtype, cin, cout, ks * ks)
     sc, sh = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1
-    st = torch.zeros(8, 2, cout, device=dev) if stats else None
+    st = ops.stats_buffer(cout, dev) if stats else None
     src = ops.Lazy(x, sc, sh, True, 0.01) if prologue else ops.Lazy(x)
-    us = timeit(lambda: ops.conv_fwd([src], wp, None, cout, out, grid=(N, 1, H, H), in_dims=(1, H, H), ksize=ks, stride=1, dims=2, stats=st, stats_reps=8))
+    us = timeit(lambda: ops.conv_fwd([src], wp, None, cout, out, grid=(N, 1, H, H), in_dims=(1, H, H), ksize=ks, stride=1, dims=2, stats=st))
     esz = 2 if dtype == torch.bfloat16 else 4
     by = N * H * H * (cin + cout) * esz
     fl = 2.0 * N * H * H * cin * cout * ks * ks

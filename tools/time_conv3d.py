@@ -13,9 +13,9 @@ def conv3d_case(N, D, H, W, cin, cout, dtype=torch.bfloat16, stats=1, prologue=1
     w = torch.randn(cout, cin, 3, 3, 3, device=dev) / 20
     wp = ops.pack_weights(w, L.PACK_CONV_FWD, dtype, cin, cout, 27)
     sc, sh = torch.rand(cin, device=dev) + 0.5, torch.randn(cin, device=dev) * 0.1
-    st = torch.zeros(8, 2, cout, device=dev) if stats else None
+    st = ops.stats_buffer(cout, dev) if stats else None
     src = ops.Lazy(x, sc, sh, True, 0.0) if prologue else ops.Lazy(x)
-    us = timeit(lambda: ops.conv_fwd([src], wp, None, cout, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=3, stats=st, stats_reps=8))
+    us = timeit(lambda: ops.conv_fwd([src], wp, None, cout, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=3, stats=st))
     esz = 2 if dtype == torch.bfloat16 else 4
     by = N * D * H * W * (cin + cout) * esz
     fl = 2.0 * N * D * H * W * cin * cout * 27
