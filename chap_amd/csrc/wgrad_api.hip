@@ -1,4 +1,5 @@
 // chap_wgrad: split selection, workspace sizing, launch, deterministic slab reduction.
+#include <cstdlib>
 #include "common.h"
 
 int chap_wgrad_launch_bf16(const chap_wgrad_params* p, int KC, float* ws, float* ws_db, int nsplit, int Ca, int Cb, hipStream_t s);
@@ -19,8 +20,17 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     const int TH = small_tile ? 4 : 8;
     q->ntiles = (long)p->N * p->D * cdiv(p->H, TH) * cdiv(p->W, 16);
     const long pairs = (long)(q->Ca / q->KC) * cdiv(q->Cb, q->Cb <= 16 ? 16 : 32);
-    long ns = 256 / pairs;       // persistent, pipelined blocks: about one per CU (measured on the whole iteration: 64 / 128 / 192 / 256 / 384 / 512 /
-                                 // 1024 target blocks -> 9.4 / 7.9 / 7.6 / 7.5 / 7.7 / 7.8 / 8.1 ms per 2D step); fewer splits = fewer slab bytes to reduce
+    // Persistent, pipelined blocks.  A block has ONE tile in flight beside the one it computes (a few KB), so what bounds the
+    // small-channel layers (most of the bytes) is memory-level parallelism: 256 blocks keep ~1.3 MB in flight on the whole chip
+    // = 0.8-0.9 TB/s measured (profiles/r02_shapes2d_baseline.csv).  Their slabs are tiny (9-37 KB), so they take as many
+    // blocks as stay resident (LDS: 3 per CU with 16-channel chunks, 2 with 32); the wide layers keep ~one block per CU
+    // (measured on the whole iteration in round 1: more splits there only add slab bytes to reduce).
+    long target = 256;
+    const size_t slab_bytes = (size_t)q->taps * q->Ca * q->Cb * sizeof(float);
+    const char* env = getenv("CHAP_WGRAD_BLOCKS");          // lab knob (tools/shape_table.py sweeps)
+    if (env && atol(env) > 0) target = atol(env);
+    else if (slab_bytes <= (size_t)64 << 10) target = q->KC == 16 ? 768 : 512;
+    long ns = target / pairs;
     if (ns < 1) ns = 1;
     if (ns > q->ntiles) ns = q->ntiles;
     q->slab = (size_t)q->taps * q->Ca * q->Cb * sizeof(float);

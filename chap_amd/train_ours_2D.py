@@ -5,7 +5,8 @@ and `log.txt` (:567-570) under `snapshot_path`.
 
 What is NOT here (out of scope): the ACDC h5 readers, RandomGenerator augmentation, TensorBoard /
 wandb.  The data layer is an argument: `args["trainloader"]` / `args["val_volumes"]` may carry any iterable of
-{'image': [B,1,H,W] fp32, 'label': [B,H,W]} dicts / list of (image [S,H,W], label [S,H,W]) arrays; without them the
+{'image': [B,1,H,W] fp32, 'label': [B,H,W]} dicts / list of (image [1,S,H,W], label [1,S,H,W]) tensors (what the reference's
+valloader yields, :274); without them the
 fixed-seed synthetic generator of chap_amd.synthetic stands in (there is no dataset on the GPU box)."""
 import csv
 import logging
@@ -53,7 +54,7 @@ def train(args, snapshot_path):
     val = a.get("val_volumes")
     if val is None:
         vi, vl = synthetic_batch(a["seed"] + 4242, 8, 0, *a["image_size"], a["num_classes"])
-        val = [(vi[:, 0].numpy(), vl.numpy())]
+        val = [(vi[:, 0].unsqueeze(0), vl.unsqueeze(0))]
     best, captured = 0.0, False
     for sampled_batch in loader:                                                 # :301-302
         volume_batch = sampled_batch["image"].to(device, non_blocking=True)
