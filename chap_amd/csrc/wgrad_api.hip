@@ -20,16 +20,20 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     const int TH = small_tile ? 4 : 8;
     q->ntiles = (long)p->N * p->D * cdiv(p->H, TH) * cdiv(p->W, 16);
     const long pairs = (long)(q->Ca / q->KC) * cdiv(q->Cb, q->Cb <= 16 ? 16 : 32);
-    // Persistent, pipelined blocks.  A block has ONE tile in flight beside the one it computes (a few KB), so what bounds the
-    // small-channel layers (most of the bytes) is memory-level parallelism: 256 blocks keep ~1.3 MB in flight on the whole chip
-    // = 0.8-0.9 TB/s measured (profiles/r02_shapes2d_baseline.csv).  Their slabs are tiny (9-37 KB), so they take as many
-    // blocks as stay resident (LDS: 3 per CU with 16-channel chunks, 2 with 32); the wide layers keep ~one block per CU
-    // (measured on the whole iteration in round 1: more splits there only add slab bytes to reduce).
+    // Persistent, pipelined blocks.  What bounds the small-channel layers (most of the bytes) is memory-level parallelism --
+    // a block keeps a few KB in flight -- so they take as many blocks as stay resident (LDS: 3 per CU with 16-channel chunks,
+    // 2 with 32); their slabs are tiny (9-37 KB).  The wide layers keep about one block per CU: more splits only add slab
+    // bytes to reduce.  Targets measured per layer shape (tools/shape_table.py --only wgrad with CHAP_WGRAD_BLOCKS = 256 / 512 /
+    // 768 / 1024 / 2048, gpurun_out/wgrad_sweep*.log): e.g. 16->16 at 256x256 58 / 41 / 37 / 43 / 49 us, 16+16->16 80 / 55 / 65 / 60 /
+    // 72, 32+32->32 at 128x128 47 / 35 / 44 / 44 / 58, k2 s2 layers 17-23 / 20-25 / 24-28; 3D 16->16 at 112x112x80 209 / 129 / - / 134 / 145,
+    // 3D 32->32 at 56x56x40 67 / 79 / - / 80 / 79.
     long target = 256;
-    const size_t slab_bytes = (size_t)q->taps * q->Ca * q->Cb * sizeof(float);
-    const char* env = getenv("CHAP_WGRAD_BLOCKS");          // lab knob (tools/shape_table.py sweeps)
+    const bool d3 = p->dims == 3;
+    const char* env = getenv("CHAP_WGRAD_BLOCKS");          // lab knob for those sweeps
     if (env && atol(env) > 0) target = atol(env);
-    else if (slab_bytes <= (size_t)64 << 10) target = q->KC == 16 ? 768 : 512;
+    else if (p->ksize == 2) target = 256;
+    else if (q->KC == 16) target = d3 ? 512 : 768;
+    else if (!d3 && (p->na == 2 || q->Ca <= 32)) target = 512;
     long ns = target / pairs;
     if (ns < 1) ns = 1;
     if (ns > q->ntiles) ns = q->ntiles;
