@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--size3d", type=int, nargs=3, default=[112, 112, 80])
     ap.add_argument("--vat-iters", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dp-fold", action="store_true", help="data-parallel: fold bucket 1 into bucket 0 and all-reduce once at the end (no overlap)")
+    ap.add_argument("--master-port", type=int, default=29531)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)       # ~13 s of CPU work at 2D config 1 (9.4 vol/s on 16 cores)
     return ap.parse_args()
@@ -138,6 +140,58 @@ def dominant_kernel_roofline(model, dtype, N, H):
             "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": alg_bytes}
 
 
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}      # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def top_kernel_roofline(dtype, N, cfg):
+    """The kernel INSTANCE with the largest share of the iteration's kernel time (profiles/r02_bench*_kernel_stats.csv): the
+    deep-layer conv `conv_fwd_kernel<bf16,3,1,KC32,NT2,MR2>` (2D, the 32..256-channel 3x3 layers) / the z-brick kernel of the
+    64..128-channel 3x3x3 layers (3D), timed live on its most frequent layer shape -- 128->128 at 32x32 (2D), 64->64 at
+    28x28x20 (3D) -- as a captured graph of back-to-back launches (the kernel is shorter than a Python launch).  MFMA-bound by
+    arithmetic intensity (576 FLOP/B in bf16), so the fraction is against the dense MFMA peak."""
+    from chap_amd import _lib as L
+    from chap_amd import ops
+    dev = torch.device("cuda")
+    if cfg == "3d":
+        C, (D, H, W), taps, dims = 64, (28, 28, 20), 27, 3
+    else:
+        C, (D, H, W), taps, dims = 128, (1, 32, 32), 9, 2
+    x = torch.randn(N, D, H, W, C, device=dev).to(dtype)
+    out = torch.empty_like(x)
+    w = torch.randn(*([C, C] + [3] * dims), device=dev) / (C * taps) ** 0.5
+    scale, shift = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
+    stats = ops.stats_buffer(C, dev)
+    wp = ops.pack_weights(w, L.PACK_CONV_FWD, dtype, C, C, taps)
+    src = ops.Lazy(x, scale, shift, True, 0.01)
+
+    def launch():
+        ops.conv_fwd([src], wp, None, C, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=dims, stats=stats)
+
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    reps = 20
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            launch()
+    g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    flops = 2.0 * N * D * H * W * taps * C * C
+    esz = 2 if dtype == torch.bfloat16 else 4
+    tf = flops / us / 1e6
+    peak = MFMA_PEAK_TFLOPS["bf16" if esz == 2 else "fp32"]
+    return {"kernel": "conv_fwd_kernel<%s,3,1,%s,KC32> %d->%d @%s N=%d" % ("bf16" if esz == 2 else "f32", "3D z-brick" if dims == 3 else "2D,NT2,MR2", C, C,
+                                                                      "x".join(map(str, (D, H, W) if dims == 3 else (H, W))), N),
+            "bound": "mfma", "avg_launch_us": round(us, 2), "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+            "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": 2.0 * N * D * H * W * C * esz}
+
+
 def dominant_kernel_roofline_3d(dtype, N, sp):
     """3D: the 16->16 3^3 conv at full resolution (block_nine / its dgrad), KC=16, NT=1."""
     from chap_amd import _lib as L
@@ -180,15 +234,36 @@ def dominant_kernel_roofline_3d(dtype, N, sp):
             "avg_launch_us": round(us, 2), "algorithmic_bytes_per_launch": alg_bytes}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU, RCCL rendezvous on 127.0.0.1)
+    BEFORE anything in this process touches the GPU, forward rank 0's JSON line, exit with the worst child's code."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(args.master_port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, p.wait())
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     # Libraries (RCCL prints a version banner) must not pollute stdout: the contract is ONE JSON line there.
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node == --gpus (or run `python bench.py --gpus N` plainly: it starts the ranks itself)" % (args.gpus, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in chap_amd)")
     torch.cuda.set_device(local)
@@ -219,7 +294,7 @@ def main():
         step = ChapStep(model, dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters), world_size=world)
     if dist is not None:
         from chap_amd.parallel import DataParallelSync
-        step.grad_sync = DataParallelSync(step.grad_both, dist)
+        step.grad_sync = DataParallelSync(step.grad_both, dist, overlap=not args.dp_fold)
     if d3:
         vol, lab = ots.synthetic_batch_3d(1337 + rank, B // 2, B - B // 2, *sp)
     else:
@@ -264,6 +339,7 @@ def main():
             bytes_per_vol = (3.5 + K) * BF_2D[args.dtype] * (H * H) / (256 * 256)
             flops_per_vol = (3.5 + K) * F_2D * (H * H) / (256 * 256)
             roof = dominant_kernel_roofline(model, dtype, B // 2, H)
+        roof["top_kernel"] = top_kernel_roofline(dtype, B // 2, args.config)
         roof["iteration_hbm_frac_vs_ideal_fusion"] = round(vps / world * bytes_per_vol / 1e9 / HBM_PEAK_GBS, 4)
         roof["iteration_tflops"] = round(vps / world * flops_per_vol / 1e12, 2)
         wl = ("LA 3D DualDecoder3d (V-Net) bs=%d (%d lab + %d unlab) %s patches, %d perturb step(s), N_v=U" % (B, B // 2, B - B // 2, "x".join(map(str, sp)), K)) if d3 else \
@@ -272,7 +348,8 @@ def main():
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": wl,
-                           "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": use_graph, "losses_finite": finite},
+                           "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": use_graph, "losses_finite": finite,
+                           "grad_exchange": None if dist is None else ("rccl all-reduce, bucket 0 overlapped with the VAT chain" if not args.dp_fold else "rccl all-reduce of the folded buckets")},
                 "roofline": roof}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, B, sp)

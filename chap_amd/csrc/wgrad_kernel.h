@@ -29,7 +29,11 @@ __device__ __forceinline__ s16x4 lds_tr16(const bf16_t* p) {
 
 // Persistent blocks, one (A-chunk, B-chunk, split) each: the A halo and the B tile of tile i+1 are
 // fetched into registers while tile i runs on the MFMA pipe out of LDS (same scheme as conv_fwd_kernel).
-template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int BN = WG_BN>
+// PD = prefetch distance in tiles: the register sets of PD tiles are in flight while one tile is computed from LDS.  A tile
+// of the 16-channel layers is a few KB, so one tile ahead (PD = 1) leaves the kernel latency-bound (0.9-1.5 TB/s); the ring
+// costs 12 VGPRs per extra tile there.  Loads are unconditional (the tile index is clamped: the tail re-reads the block's
+// last tile from L2) so that the compiler can count the waits instead of draining the queue (see halo_issue).
+template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int BN = WG_BN, int PD = 1>
 __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, float* __restrict__ ws, float* __restrict__ ws_db,
                                                     int nsplit, int Ca, int Cb) {
     typedef conv_geom<KS, ST, D3, MR> G;
@@ -102,14 +106,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
     for (int j = 0; j < 8; ++j) dbsum[j] = 0.f;
     const bool want_db = ws_db != nullptr && chunk == 0;
 
-    halo_regs<T, UNITS, ADD2, !D3> R;
-    F braw[BUNITS]; uint2 bkeep[BUNITS]; unsigned bok = 0;
+    struct pre_t { halo_regs<T, UNITS, ADD2, !D3> R; F braw[BUNITS]; uint2 bkeep[BUNITS]; unsigned bok; int n; };
+    pre_t S[PD];                                                // register sets of the tiles in flight (compile-time indexed)
     f32x2 ba[4], bb2[4];                                        // scale/shift of this thread's 8 B channels
     const int cbB_safe = bchan_ok ? cbB : 0;
 
     // all loads unconditional (out-of-range units read the tile origin and are zeroed at commit): see halo_issue
-    auto issue = [&](long tile, int& n, int& z0, int& y0, int& x0) {
+    auto issue = [&](pre_t& Q, long tile) __attribute__((always_inline)) {
+        halo_regs<T, UNITS, ADD2, !D3>& R = Q.R;
+        F (&braw)[BUNITS] = Q.braw; uint2 (&bkeep)[BUNITS] = Q.bkeep; unsigned& bok = Q.bok;
+        int n, z0, y0, x0;
         tile_coords<G::TH, G::TW, 1>(tile, tiles_x, tiles_y, P.D, n, z0, y0, x0);
+        Q.n = n;
         halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, s0, s1, P.ID, P.IH, P.IW, n, z0, y0, x0, chunk, lanesel);
         const long gp0 = (((long)n * P.D + z0) * P.H + y0) * P.W + x0;
         const char* bb = (const char*)sb.ptr + (gp0 * sb.ld + sb.coff + cbB_safe) * (long)sizeof(T);
@@ -131,7 +139,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
             for (int j = 0; j < BUNITS; ++j) bkeep[j] = *(const uint2*)(kb + __umul24(r[j], (unsigned)sb.C));
         }
     };
-    auto commit = [&](T* halo, T* bt, int n) {
+    auto commit = [&](const pre_t& Q, T* halo, T* bt) __attribute__((always_inline)) {
+        const halo_regs<T, UNITS, ADD2, !D3>& R = Q.R;
+        const F (&braw)[BUNITS] = Q.braw; const uint2 (&bkeep)[BUNITS] = Q.bkeep; const unsigned bok = Q.bok; const int n = Q.n;
         halo_commit<T, KC, ADD2, UNITS, !D3>(R, U, halo, s0, s1, aff, plainA, n, chunk, lanesel);
         f32x2 a[4], b[4];
 #pragma unroll
@@ -182,22 +192,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
             a_off[i] = ((dz * G::HH + rowl * ST + dy) * G::HW + (xb + qq) * ST + dx) * PS + kct * 16 + 4 * pp;
         }
     }
-    int n = 0, z0 = 0, y0 = 0, x0 = 0;
-    if (my_tiles > 0) issue(split, n, z0, y0, x0);
+    const long last_tile = split + (my_tiles > 0 ? my_tiles - 1 : 0) * nsplit;      // clamp target of the unconditional prefetch
+    auto tile_of = [&](long k) __attribute__((always_inline)) { const long t = split + k * nsplit; return t < last_tile ? t : last_tile; };
+    if (my_tiles > 0) {
+#pragma unroll
+        for (int d = 0; d < PD; ++d) issue(S[d], tile_of(d));
+    }
     __syncthreads();                                            // affine caches visible
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         ba[k] = *(const f32x2*)(aff + 2 * CONV_MAX_AFFINE_C + cbB_safe + 2 * k);
         bb2[k] = *(const f32x2*)(aff + 2 * CONV_MAX_AFFINE_C + CONV_MAX_AFFINE_C / 2 + cbB_safe + 2 * k);
     }
-    if (my_tiles > 0) commit(halo0, bt0, n);
+    if (my_tiles > 0) commit(S[0], halo0, bt0);
     __syncthreads();
 
-    for (long k = 0; k < my_tiles; ++k) {
-        const T* halo = (k & 1) ? halo1 : halo0;
-        const T* btile = (k & 1) ? bt1 : bt0;
-        const bool has_next = k + 1 < my_tiles;
-        if (has_next) issue(split + (k + 1) * nsplit, n, z0, y0, x0);
+    auto compute = [&](const T* halo, const T* btile) __attribute__((always_inline)) {
 #pragma unroll 1
         for (int kc = 0; kc < NKCH; ++kc) {
             if constexpr (sizeof(T) == 2) {
@@ -249,9 +259,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
                 }
             }
         }
-        if (!has_next) break;                                   // see conv_fwd_kernel: keeps the prefetch wait-free
-        commit((k & 1) ? halo0 : halo1, (k & 1) ? bt0 : bt1, n);
+    };
+    // one tile: set `s` (tile k, already in LDS) is free -> prefetch tile k + PD into it; compute tile k; land tile k + 1
+    // (set s + 1, requested PD - 1 tiles ago) in the other LDS buffers.  Returns false after the last tile.
+    long k = 0;
+    auto body = [&](auto s_const) __attribute__((always_inline)) -> bool {
+        constexpr int s = decltype(s_const)::value;
+        issue(S[s], tile_of(k + PD));
+        compute((k & 1) ? halo1 : halo0, (k & 1) ? bt1 : bt0);
+        if (k + 1 >= my_tiles) return false;                    // see conv_fwd_kernel: leave BEFORE the commit
+        commit(S[(s + 1) % PD], (k & 1) ? halo0 : halo1, (k & 1) ? bt0 : bt1);
         __syncthreads();
+        ++k;
+        return true;
+    };
+    if (my_tiles > 0) {
+        for (;;) {
+            if (!body(std::integral_constant<int, 0>{})) break;
+            if constexpr (PD > 1) { if (!body(std::integral_constant<int, 1 % PD>{})) break; }
+            if constexpr (PD > 2) { if (!body(std::integral_constant<int, 2 % PD>{})) break; }
+            if constexpr (PD > 3) { if (!body(std::integral_constant<int, 3 % PD>{})) break; }
+        }
     }
     // ---- partial slab: ws[split][tap][kc_global][kn_global]; lane holds rows 4g+j (kc), col l15 (kn) ----
     float* slab = ws + (long)split * G::NTAPS * Ca * Cb;

@@ -4,28 +4,48 @@ The reference has no distributed code; this is the build
 each rank runs the whole iteration on its own (labeled + unlabeled) shard -- BatchNorm statistics
 and Dice sums stay per replica (DDP semantics) -- and the ONLY exchange is a sum of the gradients.
 
-The two gradient buckets of an iteration (bucket 0: BCP / mix_loss backward, bucket 1: VAT final
-backward; they are produced concurrently on two streams) are the two halves of ONE contiguous fp32
-buffer.  Only their SUM matters to the optimizer, so the exchange first folds bucket 1 into bucket 0 (one
-axpy kernel + a memset) and all-reduces that half alone: 10.3 MB (2D) / 49.4 MB (3D) per step instead of
-twice that -- the ring all-reduce is per-link bound on the xGMI mesh, so bytes are what it costs.  One flat
-collective instead of per-tensor ones for the same reason.  The fused SGD kernel then consumes
-(bucket0 + bucket1) * (1/world) with bucket 1 all zero.  With HIP-graph replay the iteration is two graphs
-(compute, optimizer) with the fold and the collective in between, so RCCL never has to be captured.
+The two gradient buckets of an iteration (bucket 0: BCP / mix_loss backward = phase B, bucket 1: VAT final
+backward (+ fp_loss) = phase V; they are produced concurrently on two streams) are the two halves of ONE
+contiguous fp32 buffer, and only their SUM matters to the optimizer (the fused SGD consumes
+(bucket0 + bucket1) * (1/world)).  Two schedules:
+
+* overlap (default, what north_star names): phase B finishes long before the VAT chain -- its bucket is all-reduced on
+  phase B's stream as soon as it is final (`start_first`), BESIDE the VAT forward/backward passes; bucket 1 follows
+  when the chain is done (`start`).  Exposed on the critical path: the all-reduce of bucket 1 only (10.3 MB 2D / 49.4 MB
+  3D), with twice those bytes on the links in total.
+* fold (overlap=False): bucket 1 is folded into bucket 0 (one axpy kernel + a memset) at the end and that half alone is
+  all-reduced: the same exposed bytes, half the link traffic, nothing overlapped.
+
+With HIP-graph replay RCCL is never captured: the iteration is [graph A] -> [graph B on the side stream | graph V] with
+the eager collectives behind graph B / graph V, then [optimizer graph] (chap_amd.train.ChapStep.capture).
 """
 import torch
 
 
 class DataParallelSync:
-    def __init__(self, both_buckets, dist, group=None):
-        self.buf, self.dist, self.group = both_buckets, dist, group
-        self.work = None
+    def __init__(self, both_buckets, dist, group=None, overlap=True):
+        self.buf, self.dist, self.group, self.overlap = both_buckets, dist, group, overlap
+        self.work, self.work0 = None, None
+
+    def _halves(self):
+        n = self.buf.numel() // 2
+        return self.buf[:n], self.buf[n:]
+
+    def start_first(self):
+        """Bucket 0 is final on the CURRENT stream (phase B's): start its all-reduce now; it runs beside whatever the
+        other streams still compute (the VAT chain).  No-op in the fold schedule."""
+        if not self.overlap:
+            return
+        b0, _ = self._halves()
+        self.work0 = self.dist.all_reduce(b0, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def start(self):
-        """All gradients have been enqueued on the current stream: fold bucket 1 into bucket 0 and start the
-        (asynchronous) all-reduce of bucket 0."""
-        n = self.buf.numel() // 2
-        b0, b1 = self.buf[:n], self.buf[n:]
+        """All gradients have been enqueued on the current stream: all-reduce what is still outstanding (bucket 1 when
+        bucket 0 went ahead with start_first; otherwise fold bucket 1 into bucket 0 and all-reduce that half)."""
+        b0, b1 = self._halves()
+        if self.work0 is not None:
+            self.work = self.dist.all_reduce(b1, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return
         if b0.is_cuda:
             from . import ops
             ops.perturb(b0, b1, b0, 1.0)            # b0 += b1 (chap_perturb: out = x + alpha * d)
@@ -35,6 +55,8 @@ class DataParallelSync:
         self.work = self.dist.all_reduce(b0, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def wait(self):
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
+        """The current stream (the optimizer's) waits for the collectives."""
+        for w in (self.work0, self.work):
+            if w is not None:
+                w.wait()
+        self.work0 = self.work = None

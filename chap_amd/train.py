@@ -7,6 +7,7 @@ Pieces that are ABSENT from the reference (losses.VAT2d, patch.create_maskV1, lo
 ramps.sigmoid_rampup) follow the definitions in DESIGN.md (P1-P4); the CPU oracle restates the same
 definitions (oracle/train_step.py).
 """
+import contextlib
 import math
 
 import numpy as np
@@ -173,7 +174,7 @@ class ChapStep:
         self.iter_num = 0
         self.world_size = world_size
         self.grad_sync = None                   # parallel.DataParallelSync (world_size > 1)
-        self._graph = None
+        self._graph, self._graph_opt, self._graphs_dp = None, None, None
         # --dropout: per-level channel scores [C_l] = gradsim.get_sim() (train_ours_2D.py:360), refreshed every iteration by
         # gradsim.get_grad_convkernel (:365); all-zero (the initial value) = the Dropout2d pair (FilterDropout.py:71-73).
         # `sim_score` (or inject['sim_score']) overrides them.
@@ -264,122 +265,138 @@ class ChapStep:
         self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad2)
 
     def device_step(self, volume_batch, label_batch, inject=None, update=True):
+        """The device work of one iteration on the current stream (+ the side streams): phase A (pass A, pseudo labels,
+        perturbation mask), then phase B (largest-CC filter, BCP mixing, pass B forward / backward -> gradient bucket 0) on a
+        side stream BESIDE phase V (the VAT chain -> bucket 1) on this one, then the gradient exchange and the optimizer."""
         with self.model.hold_stat_shift():          # one snapshot of the running means for all passes of the iteration (determinism)
-            return self._device_step(volume_batch, label_batch, inject, update)
+            return self._iteration(volume_batch, label_batch, inject, update)
 
-    def _device_step(self, volume_batch, label_batch, inject=None, update=True):
-        a, model = self.args, self.model
-        inject = inject or {}
-        nc = a["num_classes"]
-        lbs = a["labeled_bs"]
-        B = volume_batch.shape[0]
-        lsub, usub = lbs // 2, (B - lbs) // 2
-        img_a, img_b = volume_batch[:lsub], volume_batch[lsub:lbs]
-        uimg_a, uimg_b = volume_batch[lbs:lbs + usub], volume_batch[lbs + usub:]
-        lab_a, lab_b = label_batch[:lsub], label_batch[lsub:lbs]
-        uimg_ab = volume_batch[lbs:]
-
+    def _iteration(self, volume_batch, label_batch, inject=None, update=True):
         main = torch.cuda.current_stream()
-        capturing = torch.cuda.is_current_stream_capturing()
-        if self.concurrent and capturing:
-            self._d2.wait_stream(main)                           # enters the capture from the origin stream
-            model._exec._capture_sides = {main.cuda_stream: self._d2}
-        # ---- pass A: pseudo labels from both decoders (no grad), train_ours_2D.py:314-330
-        with torch.no_grad():
-            pre_ab1, pre_ab2 = model(uimg_ab, drop_masks=inject.get("drop_A"))
-            outputs_soft1, outputs_soft2, pseudo_outputs1, pseudo_outputs2, knowledge = ops.pseudo_block(pre_ab1, pre_ab2)
-
-        # ---- largest-CC filter, loss mask and BCP mixing (:326-338) feed pass B only: they run at the head of the
-        #      pass-B branch, off the critical path (the VAT branch needs the soft / arg-max outputs, not these)
-        def mix_inputs():
-            with torch.no_grad():
-                if a["nms"]:
-                    plab1 = ops.largest_cc(pseudo_outputs1, nc)
-                    plab2 = ops.largest_cc(pseudo_outputs2, nc)
-                else:
-                    plab1, plab2 = pseudo_outputs1, pseudo_outputs2
-                loss_mask = torch.empty(lsub, *volume_batch.shape[2:], dtype=torch.int64, device=volume_batch.device)
-                ops.box_mask(loss_mask, self.box)
-                # BCP mixing (:335-338): net_input_mix = cat(net_input_l, net_input_unl)
-                net_input_mix = torch.empty((lsub + usub,) + tuple(volume_batch.shape[1:]), dtype=torch.float32, device=volume_batch.device)
-                ops.box_mix(img_b, uimg_b, net_input_mix[:lsub], self.box)       # img_b*mask + uimg_b*(1-mask)
-                ops.box_mix(uimg_a, img_a, net_input_mix[lsub:], self.box)       # uimg_a*mask + img_a*(1-mask)
-            return plab1, plab2, loss_mask, net_input_mix
-
-        # ---- pass B + the four mix_loss terms (:339-351)
-        def pass_b():
-            plab1, plab2, loss_mask, net_input_mix = mix_inputs()
-            plab_a1, plab_b1 = plab1[:usub], plab1[usub:]
-            plab_a2, plab_b2 = plab2[:usub], plab2[usub:]
-            out_mix1, out_mix2 = model(net_input_mix, drop_masks=inject.get("drop_B"))
-            d1, d2 = torch.empty_like(out_mix1), torch.empty_like(out_mix2)
-            terms = (  # (logits, dlogits, img_l, patch_l, unlab)
-                (out_mix1[lsub:], d1[lsub:], plab_a2, lab_a, True),      # mix_loss1: out_unl1
-                (out_mix2[lsub:], d2[lsub:], plab_a1, lab_a, True),      # mix_loss2: out_unl2
-                (out_mix1[:lsub], d1[:lsub], lab_b, plab_b2, False),     # mix_loss3: out_l1
-                (out_mix2[:lsub], d2[:lsub], lab_b, plab_b1, False),     # mix_loss4: out_l2
-            )
-            losses = []
-            split = self.gradsim is not None and inject.get("sim_score") is None and self.sim_score is None
-            if split:       # loss_l / loss_u (:352-353) are taken apart: d*_u holds the unlabeled-supervised parts' gradient
-                e1, e2 = torch.empty_like(out_mix1), torch.empty_like(out_mix2)
-                eterms = (e1[lsub:], e2[lsub:], e1[:lsub], e2[:lsub])
-            for ti, (lg, dl, img_l, patch_l, unlab) in enumerate(terms):
-                iw, pw = (0.5, 1.0) if unlab else (1.0, 0.5)            # l_weight=1.0, u_weight=0.5 (:198-203)
-                loss3, acc = ops.mix_loss_fwd(lg, img_l, patch_l, loss_mask, iw, pw)
-                if split:   # (loss_image, loss_patch) = (loss_u_out, loss_l_in) for the unlabeled rows, (loss_l_out, loss_u_in) for the labeled ones (:345-349)
-                    wl, wu = ((0.0, pw), (iw, 0.0)) if unlab else ((iw, 0.0), (0.0, pw))
-                    ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, wl[0], wl[1], acc, dl)
-                    ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, wu[0], wu[1], acc, eterms[ti])
-                else:
-                    ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, iw, pw, acc, dl)
-                losses.append(loss3)
-            if not split:
-                torch.autograd.backward([out_mix1, out_mix2], [d1, d2])
-                return losses
-            # two backward passes over the saved forward (linear in dlogits): gradients of loss_l and of loss_u into their own
-            # buffers -> the channel scores of the NEXT iteration (gradsim.get_grad_convkernel, :365); their sum is the BCP
-            # gradient the single pass would have produced
-            n_ = self._grad_lu.numel() // 2
-            g_l, g_u = self._grad_lu[:n_], self._grad_lu[n_:]
-            self._grad_lu.zero_()
-            model.backward_saved(out_mix1, [d1, d2], g_l)
-            model.backward_saved(out_mix1, [e1, e2], g_u)
-            model.release_saved(out_mix1)
-            self._new_scores_from = (g_l, g_u)
-            b0 = self.grad_both[:n_]
-            ops.perturb(b0, g_l, b0, 1.0)
-            ops.perturb(b0, g_u, b0, 1.0)
-            return losses
-
-        # ---- the VAT branch (:368-375) depends only on pass A: it and pass B run side by side on two streams and
-        #      accumulate their parameter gradients into separate buckets (VAT: the second one)
-        vat_loss = None
-        if a["adv_noise"]:
-            diff_mask = ops.diff_mask(pseudo_outputs1, pseudo_outputs2, knowledge, 4, a["topk1"])
-        if self.concurrent and a["adv_noise"]:
-            self._side.wait_stream(main)
-            with torch.cuda.stream(self._side):
-                losses = pass_b()
-            vat_loss = self.adv_loss(model, volume_batch, outputs_soft1, outputs_soft2, diff_mask, a["adv_losstype"],
-                                     weight_dev=self.cw_dev, inject=inject, grad_buffer=self.grad2)
-            main.wait_stream(self._side)
-        else:
-            losses = pass_b()
-            if a["adv_noise"]:
-                vat_loss = self.adv_loss(model, volume_batch, outputs_soft1, outputs_soft2, diff_mask, a["adv_losstype"],
-                                         weight_dev=self.cw_dev, inject=inject, grad_buffer=self.grad2)
-        if self.concurrent and capturing:
-            main.wait_stream(self._d2)
-            model._exec._capture_sides = {}
-        if vat_loss is None:
-            vat_loss = torch.zeros(1, dtype=torch.float32, device=volume_batch.device)
+        with self._decoder_fork(main):
+            ctx = self._phase_a(volume_batch, label_batch, inject)
+            if self.concurrent and self.args["adv_noise"]:
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    losses = self._phase_b(ctx)
+                    if self.grad_sync is not None and update and not torch.cuda.is_current_stream_capturing():
+                        self.grad_sync.start_first()        # bucket 0 is final: its all-reduce runs beside the VAT chain
+                vat_loss = self._phase_v(ctx)
+                main.wait_stream(self._side)
+            else:
+                losses = self._phase_b(ctx)
+                vat_loss = self._phase_v(ctx)
         out = {"mix_losses": losses, "vat_loss": vat_loss}
-        if a["dropout"]:
-            out["fp_losses"] = self._fp_branch(uimg_ab, pseudo_outputs1, pseudo_outputs2, inject, capturing)
+        if self.args["dropout"]:
+            out["fp_losses"] = self._fp_branch(ctx["uimg_ab"], ctx["pseudo_outputs1"], ctx["pseudo_outputs2"], ctx["inject"], None)
         if update:
             self.exchange_and_update()
         return out
+
+    @contextlib.contextmanager
+    def _decoder_fork(self, origin):
+        """Under capture: let the executor run the second decoder of the passes on `origin` on a stream forked from it (a
+        captured stream may fork / join with the capture's ORIGIN stream only, see __init__)."""
+        capturing = self.concurrent and torch.cuda.is_current_stream_capturing()
+        if capturing:
+            self._d2.wait_stream(origin)
+            self.model._exec._capture_sides = {origin.cuda_stream: self._d2}
+        try:
+            yield
+        finally:
+            if capturing:
+                origin.wait_stream(self._d2)
+                self.model._exec._capture_sides = {}
+
+    def _phase_a(self, volume_batch, label_batch, inject):
+        a, model = self.args, self.model
+        inject = inject or {}
+        lbs = a["labeled_bs"]
+        B = volume_batch.shape[0]
+        lsub, usub = lbs // 2, (B - lbs) // 2
+        ctx = dict(inject=inject, volume_batch=volume_batch, lsub=lsub, usub=usub,
+                   img_a=volume_batch[:lsub], img_b=volume_batch[lsub:lbs], uimg_a=volume_batch[lbs:lbs + usub], uimg_b=volume_batch[lbs + usub:],
+                   lab_a=label_batch[:lsub], lab_b=label_batch[lsub:lbs], uimg_ab=volume_batch[lbs:])
+        # ---- pass A: pseudo labels from both decoders (no grad), train_ours_2D.py:314-330
+        with torch.no_grad():
+            pre_ab1, pre_ab2 = model(ctx["uimg_ab"], drop_masks=inject.get("drop_A"))
+            soft1, soft2, pseudo1, pseudo2, knowledge = ops.pseudo_block(pre_ab1, pre_ab2)
+        ctx.update(outputs_soft1=soft1, outputs_soft2=soft2, pseudo_outputs1=pseudo1, pseudo_outputs2=pseudo2, knowledge=knowledge)
+        # ---- the VAT branch (:368-375) depends only on pass A: it and pass B run side by side on two streams and
+        #      accumulate their parameter gradients into separate buckets (VAT: the second one)
+        if a["adv_noise"]:
+            ctx["diff_mask"] = ops.diff_mask(pseudo1, pseudo2, knowledge, 4, a["topk1"])
+        return ctx
+
+    def _phase_b(self, ctx):
+        """Largest-CC filter, loss mask and BCP mixing (:326-338) feed pass B only: they run at the head of this branch, off
+        the critical path (the VAT branch needs the soft / arg-max outputs, not these); then pass B and the four mix_loss
+        terms (:339-351), backward into gradient bucket 0."""
+        a, model, inject = self.args, self.model, ctx["inject"]
+        nc = a["num_classes"]
+        lsub, usub, volume_batch = ctx["lsub"], ctx["usub"], ctx["volume_batch"]
+        with torch.no_grad():
+            if a["nms"]:
+                plab1 = ops.largest_cc(ctx["pseudo_outputs1"], nc)
+                plab2 = ops.largest_cc(ctx["pseudo_outputs2"], nc)
+            else:
+                plab1, plab2 = ctx["pseudo_outputs1"], ctx["pseudo_outputs2"]
+            loss_mask = torch.empty(lsub, *volume_batch.shape[2:], dtype=torch.int64, device=volume_batch.device)
+            ops.box_mask(loss_mask, self.box)
+            # BCP mixing (:335-338): net_input_mix = cat(net_input_l, net_input_unl)
+            net_input_mix = torch.empty((lsub + usub,) + tuple(volume_batch.shape[1:]), dtype=torch.float32, device=volume_batch.device)
+            ops.box_mix(ctx["img_b"], ctx["uimg_b"], net_input_mix[:lsub], self.box)       # img_b*mask + uimg_b*(1-mask)
+            ops.box_mix(ctx["uimg_a"], ctx["img_a"], net_input_mix[lsub:], self.box)       # uimg_a*mask + img_a*(1-mask)
+        lab_a, lab_b = ctx["lab_a"], ctx["lab_b"]
+        plab_a1, plab_b1 = plab1[:usub], plab1[usub:]
+        plab_a2, plab_b2 = plab2[:usub], plab2[usub:]
+        out_mix1, out_mix2 = model(net_input_mix, drop_masks=inject.get("drop_B"))
+        d1, d2 = torch.empty_like(out_mix1), torch.empty_like(out_mix2)
+        terms = (  # (logits, dlogits, img_l, patch_l, unlab)
+            (out_mix1[lsub:], d1[lsub:], plab_a2, lab_a, True),      # mix_loss1: out_unl1
+            (out_mix2[lsub:], d2[lsub:], plab_a1, lab_a, True),      # mix_loss2: out_unl2
+            (out_mix1[:lsub], d1[:lsub], lab_b, plab_b2, False),     # mix_loss3: out_l1
+            (out_mix2[:lsub], d2[:lsub], lab_b, plab_b1, False),     # mix_loss4: out_l2
+        )
+        losses = []
+        split = self.gradsim is not None and inject.get("sim_score") is None and self.sim_score is None
+        if split:       # loss_l / loss_u (:352-353) are taken apart: e* holds the unlabeled-supervised parts' gradient
+            e1, e2 = torch.empty_like(out_mix1), torch.empty_like(out_mix2)
+            eterms = (e1[lsub:], e2[lsub:], e1[:lsub], e2[:lsub])
+        for ti, (lg, dl, img_l, patch_l, unlab) in enumerate(terms):
+            iw, pw = (0.5, 1.0) if unlab else (1.0, 0.5)            # l_weight=1.0, u_weight=0.5 (:198-203)
+            loss3, acc = ops.mix_loss_fwd(lg, img_l, patch_l, loss_mask, iw, pw)
+            if split:   # (loss_image, loss_patch) = (loss_u_out, loss_l_in) for the unlabeled rows, (loss_l_out, loss_u_in) for the labeled ones (:345-349)
+                wl, wu = ((0.0, pw), (iw, 0.0)) if unlab else ((iw, 0.0), (0.0, pw))
+                ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, wl[0], wl[1], acc, dl)
+                ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, wu[0], wu[1], acc, eterms[ti])
+            else:
+                ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, iw, pw, acc, dl)
+            losses.append(loss3)
+        if not split:
+            torch.autograd.backward([out_mix1, out_mix2], [d1, d2])
+            return losses
+        # two backward passes over the saved forward (linear in dlogits): gradients of loss_l and of loss_u into their own
+        # buffers -> the channel scores of the NEXT iteration (gradsim.get_grad_convkernel, :365); their sum is the BCP
+        # gradient the single pass would have produced
+        n_ = self._grad_lu.numel() // 2
+        g_l, g_u = self._grad_lu[:n_], self._grad_lu[n_:]
+        self._grad_lu.zero_()
+        model.backward_saved(out_mix1, [d1, d2], g_l)
+        model.backward_saved(out_mix1, [e1, e2], g_u)
+        model.release_saved(out_mix1)
+        self._new_scores_from = (g_l, g_u)
+        b0 = self.grad_both[:n_]
+        ops.perturb(b0, g_l, b0, 1.0)
+        ops.perturb(b0, g_u, b0, 1.0)
+        return losses
+
+    def _phase_v(self, ctx):
+        a = self.args
+        if not a["adv_noise"]:
+            return torch.zeros(1, dtype=torch.float32, device=ctx["volume_batch"].device)
+        return self.adv_loss(self.model, ctx["volume_batch"], ctx["outputs_soft1"], ctx["outputs_soft2"], ctx["diff_mask"], a["adv_losstype"],
+                             weight_dev=self.cw_dev, inject=ctx["inject"], grad_buffer=self.grad2)
 
     def _fp_branch(self, uimg_ab, pseudo1, pseudo2, inject, capturing):
         """"2) fp" of the loop (train_ours_2D.py:359-365, default off): both decoders on the channel-perturbed features
@@ -446,30 +463,80 @@ class ChapStep:
             self.load_state_dict(snap)
             torch.cuda.synchronize()
         self.model._rng.reset_counter()
-        g = torch.cuda.CUDAGraph()
         self.prepare()
+        if self.grad_sync is not None and type(self)._iteration is ChapStep._iteration and self.concurrent and self.args["adv_noise"]:
+            return self._capture_dp(inject)
+        g = torch.cuda.CUDAGraph()
         dp = self.grad_sync is not None
         # thread_local: the RCCL watchdog thread polls events while we capture (global mode would abort on that)
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self.model._rng.seed_dev.add_(1)
             self._static_out = self.device_step(self._static_v, self._static_l, inject, update=not dp)
-        self._graph, self._graph_opt = g, None
-        if dp:          # data-parallel: [compute graph] -> RCCL all-reduce (eager) -> [optimizer graph]
+        self._graph, self._graph_opt, self._graphs_dp = g, None, None
+        if dp:          # data-parallel without the two-branch schedule: [compute graph] -> RCCL all-reduce (eager) -> [optimizer graph]
             g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode="thread_local"):
                 self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad2)
             self._graph_opt = g2
         return g
 
+    def _capture_dp(self, inject):
+        """Data-parallel capture: the iteration as FOUR graphs so that RCCL (never captured) can run between them and the
+        all-reduce of bucket 0 overlaps the VAT chain (north_star):
+
+            main:  [A: pass A, pseudo labels, mask] -> [V: VAT chain -> bucket 1] -> all-reduce(bucket 1) ----+-> [optimizer]
+            side:                       wait A -> [B: LCC, BCP mix, pass B -> bucket 0] -> all-reduce(bucket 0) --^
+
+        B and V are captured into SEPARATE memory pools (they run concurrently at replay: sharing a pool would let one
+        reuse memory the other has freed during capture); what crosses graph boundaries (pass A's outputs) is kept alive
+        by `self._dp_ctx`.  Each capture's origin stream forks its own second-decoder stream."""
+        kw = dict(capture_error_mode="thread_local")
+        stack = contextlib.ExitStack()
+        gA, gB, gV, gO = (torch.cuda.CUDAGraph() for _ in range(4))
+        with torch.cuda.graph(gA, **kw):
+            self.model._rng.seed_dev.add_(1)
+            stack.enter_context(self.model.hold_stat_shift())       # the snapshot copy is a node of graph A; held until V is captured
+            with self._decoder_fork(torch.cuda.current_stream()):
+                ctx = self._phase_a(self._static_v, self._static_l, inject)
+        with torch.cuda.graph(gB, **kw):
+            with self._decoder_fork(torch.cuda.current_stream()):
+                losses = self._phase_b(ctx)
+        with torch.cuda.graph(gV, **kw):
+            with self._decoder_fork(torch.cuda.current_stream()):
+                vat_loss = self._phase_v(ctx)
+            out = {"mix_losses": losses, "vat_loss": vat_loss}
+            if self.args["dropout"]:
+                out["fp_losses"] = self._fp_branch(ctx["uimg_ab"], ctx["pseudo_outputs1"], ctx["pseudo_outputs2"], ctx["inject"], None)
+        stack.close()
+        with torch.cuda.graph(gO, **kw):
+            self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad2)
+        self._dp_ctx, self._static_out = ctx, out
+        self._graph, self._graph_opt, self._graphs_dp = None, None, (gA, gB, gV, gO)
+        return gA
+
     def replay(self, volume_batch, label_batch, box_yx=None):
         self._static_v.copy_(volume_batch, non_blocking=True)
         self._static_l.copy_(label_batch, non_blocking=True)
         self.prepare(box_yx)
-        self._graph.replay()
-        if self._graph_opt is not None:
+        if self._graphs_dp is not None:
+            gA, gB, gV, gO = self._graphs_dp
+            main = torch.cuda.current_stream()
+            gA.replay()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                gB.replay()
+                self.grad_sync.start_first()        # all-reduce of bucket 0 on the side stream, beside graph V
+            gV.replay()
             self.grad_sync.start()
+            main.wait_stream(self._side)
             self.grad_sync.wait()
-            self._graph_opt.replay()
+            gO.replay()
+        else:
+            self._graph.replay()
+            if self._graph_opt is not None:
+                self.grad_sync.start()
+                self.grad_sync.wait()
+                self._graph_opt.replay()
         # the optimizer inside the graph changed the weights on the device: the packed copies an EAGER forward
         # (validation, inference, step()) would otherwise reuse are stale -- the graph itself re-packs on every replay
         self.model.mark_params_dirty()
@@ -487,7 +554,7 @@ class AblationStep(ChapStep):
     unlabeled-half mask (shape-inconsistent); here, as in the main loop, VAT acts on the unlabeled half.  fp_loss (the
     `dropout` branch, :209-213) is 0 as upstream.  The consistency weight lives in device memory: capture()/replay() work."""
 
-    def _device_step(self, volume_batch, label_batch, inject=None, update=True):
+    def _iteration(self, volume_batch, label_batch, inject=None, update=True):
         a, model = self.args, self.model
         inject = inject or {}
         lbs = a["labeled_bs"]

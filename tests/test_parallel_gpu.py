@@ -1,0 +1,86 @@
+"""The RCCL side of the data-parallel iteration on real GPUs (each rank in a process of its own, tests/dp_worker.py).
+
+* one rank (any GPU box): a 1-rank NCCL group drives exactly the code path of a multi-GPU run -- eager and the four-graph
+  replay, overlap and fold schedules; the update must equal the non-DP step's bit for bit (a 1-rank sum is the identity) and
+  the fused SGD must leave both gradient buckets zeroed;
+* two ranks (skipped unless the box has >= 2 GPUs): both ranks end with IDENTICAL parameters, equal to the CPU oracle's
+  "mean of the per-shard gradients" update (DDP semantics)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+
+
+def _run(args, timeout=600):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.Popen([sys.executable, WORKER] + [str(a) for a in args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+def _wait(procs, timeout=600):
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, out.decode(errors="replace")[-4000:]
+
+
+@pytest.mark.parametrize("mode,overlap", [("eager", 1), ("graph", 1), ("graph", 0), ("eager", 0)])
+def test_one_rank_nccl_group_equals_the_plain_step(tmp_path, mode, overlap):
+    port = 29700 + os.getpid() % 200 + 2 * overlap + (1 if mode == "graph" else 0)
+    _wait([_run(["--out", tmp_path, "--mode", mode, "--overlap", overlap, "--no-dp"])])
+    _wait([_run(["--out", tmp_path, "--mode", mode, "--overlap", overlap, "--port", port])])
+    ref = torch.load(os.path.join(tmp_path, "rank0_%s_%d_nodp.pt" % (mode, overlap)))
+    got = torch.load(os.path.join(tmp_path, "rank0_%s_%d.pt" % (mode, overlap)))
+    assert float(got["buckets"].abs().max()) == 0.0                      # both buckets consumed and zeroed
+    assert got["iter_num"] == ref["iter_num"]
+    for a, b in zip(got["losses"], ref["losses"]):
+        assert torch.equal(a, b)
+    bad = [k for k in ref["model"] if not torch.equal(ref["model"][k], got["model"][k])]
+    assert not bad, bad[:5]
+    assert torch.equal(ref["mom"], got["mom"])
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_two_ranks_hold_identical_parameters_equal_to_the_mean_of_shard_gradients(tmp_path, mode):
+    from oracle import init as oinit
+    from oracle import train_step as ots
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_worker as W
+    port = 29900 + os.getpid() % 90
+    _wait([_run(["--rank", r, "--world", 2, "--out", tmp_path, "--mode", mode, "--overlap", 1, "--port", port]) for r in range(2)])
+    r0 = torch.load(os.path.join(tmp_path, "rank0_%s_1.pt" % mode))
+    r1 = torch.load(os.path.join(tmp_path, "rank1_%s_1.pt" % mode))
+    # parameters (not BatchNorm running statistics: those are per replica, DDP semantics) are identical on the two ranks
+    for k in r0["model"]:
+        if not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            assert torch.equal(r0["model"][k], r1["model"][k]), k
+    # oracle: gradients of each shard from the same initial state, averaged, ONE SGD step
+    state = oinit.dual_decoder_2d_state(301)
+    grads = []
+    for r in range(2):
+        sd = {k: v.clone() for k, v in state.items()}
+        for k, v in sd.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        moms = {k: torch.zeros_like(v) for k, v in sd.items() if v.requires_grad}
+        vol, lab, inj, box = W.shard_inputs(r)
+        grads.append(ots.iteration(sd, moms, vol, lab, box, iter_num=W.IT0, lr=0.0, args=W.ARGS, inject=inj)["grads"])
+    num = den = 0.0
+    for k, g0 in grads[0].items():
+        g = (g0 + grads[1][k]) / 2.0
+        want = state[k] - 0.01 * (g + 1e-4 * state[k])                  # first step: momentum buffer = g + wd * p
+        upd_o, upd_h = (want - state[k]).double(), (r0["model"][k] - state[k]).double()
+        num += float(((upd_o - upd_h) ** 2).sum())
+        den += float((upd_o ** 2).sum())
+    assert (num / den) ** 0.5 < 0.02, (num / den) ** 0.5
