@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--size3d", type=int, nargs=3, default=[112, 112, 80])
     ap.add_argument("--vat-iters", type=int, default=1)
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--dp-fold", action="store_true", help="data-parallel: fold bucket 1 into bucket 0 and all-reduce once at the end (no overlap)")
+    ap.add_argument("--dp-overlap", action="store_true", help="data-parallel: all-reduce bucket 0 beside the VAT chain (four-graph replay) instead of "
+                    "folding the buckets and all-reducing once at the end (default: measured faster, see DESIGN.md section 6)")
     ap.add_argument("--master-port", type=int, default=29531)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)       # ~13 s of CPU work at 2D config 1 (9.4 vol/s on 16 cores)
@@ -294,7 +295,7 @@ def main():
         step = ChapStep(model, dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters), world_size=world)
     if dist is not None:
         from chap_amd.parallel import DataParallelSync
-        step.grad_sync = DataParallelSync(step.grad_both, dist, overlap=not args.dp_fold)
+        step.grad_sync = DataParallelSync(step.grad_both, dist, overlap=args.dp_overlap)
     if d3:
         vol, lab = ots.synthetic_batch_3d(1337 + rank, B // 2, B - B // 2, *sp)
     else:
@@ -349,7 +350,7 @@ def main():
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                 "config": {"workload": wl,
                            "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": use_graph, "losses_finite": finite,
-                           "grad_exchange": None if dist is None else ("rccl all-reduce, bucket 0 overlapped with the VAT chain" if not args.dp_fold else "rccl all-reduce of the folded buckets")},
+                           "grad_exchange": None if dist is None else ("rccl all-reduce, bucket 0 overlapped with the VAT chain" if args.dp_overlap else "rccl all-reduce of the folded buckets")},
                 "roofline": roof}
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, B, sp)

@@ -196,20 +196,22 @@ def _full_size_run(cfg, dtype, steps=3):
     step.iter_num = 4500                              # consistency weight 0.449: the VAT term counts
     vol, lab = vol.to(DEV), lab.to(DEV)
     step.capture(vol, lab, warmup=2)
-    losses = []
+    losses, stats1 = [], None
     for i in range(steps):
         out = step.replay(vol, lab)
         losses.append(torch.cat([l[2:3] for l in out["mix_losses"]] + [out["vat_loss"]]).clone())
+        if i == 0:      # BatchNorm running statistics after ONE iteration from identical weights: arithmetic differences only
+            stats1 = {k: v.clone() for k, v in m.state_dict().items() if k.endswith(("running_mean", "running_var"))}
     torch.cuda.synchronize()
-    return m, step, torch.stack(losses).cpu(), (vol, lab)
+    return m, step, torch.stack(losses).cpu(), (vol, lab), stats1
 
 
 @pytest.mark.parametrize("cfg", ["2d", "3d"])
 def test_full_size_graph_path_properties(cfg):
     """The configuration bench.py times (graph replay at the BASELINE sizes), bf16 AND fp32 from the same initial state."""
-    m32, s32, l32, (vol, lab) = _full_size_run(cfg, torch.float32)
-    m16, s16, l16, _ = _full_size_run(cfg, torch.bfloat16)
-    m16b, s16b, l16b, _ = _full_size_run(cfg, torch.bfloat16)
+    m32, s32, l32, (vol, lab), st32 = _full_size_run(cfg, torch.float32)
+    m16, s16, l16, _, st16 = _full_size_run(cfg, torch.bfloat16)
+    m16b, s16b, l16b, _, _ = _full_size_run(cfg, torch.bfloat16)
     assert torch.isfinite(l32).all() and torch.isfinite(l16).all()
     # run-to-run: bitwise (no atomics anywhere; the two streams of an iteration write disjoint buffers)
     assert torch.equal(l16, l16b) and not _equal_states(m16.state_dict(), m16b.state_dict())
@@ -217,13 +219,15 @@ def test_full_size_graph_path_properties(cfg):
     bcp32, bcp16 = l32[:, :4].sum(1), l16[:, :4].sum(1)
     assert ((bcp16 - bcp32).abs() / bcp32.abs()).max() < 0.03, (bcp16, bcp32)       # measured: see DESIGN.md section 8
     assert ((l16[:, 4] - l32[:, 4]).abs() / l32[:, 4].abs().clamp_min(1e-6)).max() < 0.25, (l16[:, 4], l32[:, 4])
-    sd32, sd16 = m32.state_dict(), m16.state_dict()
-    for k in sd32:
-        if k.endswith("running_mean"):           # in units of the channel's standard deviation: measured <= 0.050 (3D), 0.02 (2D)
-            scale = sd32[k.replace("running_mean", "running_var")].sqrt()
-            assert ((sd16[k] - sd32[k]).abs() / scale).max() < 0.1, k
-        elif k.endswith("running_var"):          # variances feel the bf16 rounding of the layer's INPUT twice: measured <= 0.063 (3D), 0.03 (2D)
-            assert ((sd16[k] - sd32[k]).abs() / sd32[k].abs().clamp_min(1e-3)).max() < 0.1, k
+    # BatchNorm running statistics after the FIRST iteration (identical weights on both sides, so what differs is the bf16
+    # storage of the activations; later iterations also carry the divergence of two training trajectories through arg-max
+    # pseudo labels, which is not an arithmetic property).  One EMA update with momentum 0.1 per pass that tracks statistics.
+    for k in st32:
+        if k.endswith("running_mean"):           # in units of the channel's standard deviation
+            scale = st32[k.replace("running_mean", "running_var")].sqrt()
+            assert ((st16[k] - st32[k]).abs() / scale).max() < 5e-2, k
+        else:
+            assert ((st16[k] - st32[k]).abs() / st32[k].abs().clamp_min(1e-3)).max() < 5e-2, k
     # discrete kernels of the path at full size against the CPU oracle: arg-max pseudo labels of the trained fp32 model ->
     # largest connected component (scipy, full connectivity), BCP box mask / mixing
     with torch.no_grad():
