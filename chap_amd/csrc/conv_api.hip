@@ -1,4 +1,5 @@
 // chap_conv_fwd / chap_pack_weights: argument checks, blocking choice, weight packing kernel.
+#include <cstdlib>
 #include "common.h"
 
 #define DECL_GEOM(dt, g) int chap_conv_launch_##dt##_g##g(const chap_conv_params* p, int KC, int NT, int MR, hipStream_t s);
@@ -65,10 +66,13 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     const bool bf = p->dtype == CHAP_BF16;
     if (geom == 2 && bf) {
         // 3D 3x3x3 (measured on the V-Net shapes, tools/lab/conv_lab.hip sweeps): z-per-wave bricks (MR = 4) once
-        // the grid has >= 32 bricks, with the widest NT that still gives >= 128 blocks; the deep, tiny layers run
-        // 1 x 4 x 16 slabs with NT = 2 (two blocks per CU, weights staged through LDS).
+        // the grid has >= 64 bricks, with the widest NT that still gives >= 128 blocks; the deep, tiny layers run
+        // 1 x 4 x 16 slabs with NT = 2 (two blocks per CU, weights staged through LDS).  Round-2 sweep over (NT, MR)
+        // on the real layers (tools/lab/sweep_conv.sh, gpurun_out/conv_sweep3d.log): at 14x14x10, N = 2 (32 bricks) the slabs
+        // win -- 128->128 22.0 vs 30.2 us, 128+128->128 24.4 vs 34.7, 256->128 37.4 vs 48.7 -- at 28x28x20 (196 bricks) the bricks
+        // do (28.1 vs 41.6).
         const long bricks = (long)p->N * cdiv(p->D, 4) * cdiv(p->H, 4) * cdiv(p->W, 16);
-        if (bricks >= 32) {
+        if (bricks >= 64) {
             MR = 4;
             while (NT > 1 && bricks * cdiv(b.ntiles, NT) < 128) NT >>= 1;
         } else if (b.KC == 32 && NT > 2) {
@@ -86,6 +90,15 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
         else {
             MR = 1;
             while (NT > 1 && blocks(1, NT) < 384) NT >>= 1;
+        }
+    }
+    {   // lab knobs (tools/shape_table.py sweeps): CHAP_CONV_NT / CHAP_CONV_MR override the blocking of the k3 s1 layers with
+        // at least CHAP_CONV_MINC (default 64) input channels
+        const char* ent = getenv("CHAP_CONV_NT"); const char* emr = getenv("CHAP_CONV_MR"); const char* emc = getenv("CHAP_CONV_MINC");
+        const int minc = emc ? atoi(emc) : 64;
+        if ((geom == 1 || geom == 2) && Ck >= minc) {
+            if (ent && atoi(ent) > 0 && atoi(ent) <= b.ntiles) NT = atoi(ent);
+            if (emr && atoi(emr) > 0) MR = atoi(emr);
         }
     }
     static const conv_launch_fn table[2][5] = {

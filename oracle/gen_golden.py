@@ -394,6 +394,52 @@ def gen_filter_dropout(ref):
     np.savez_compressed(os.path.join(OUT, "filter_dropout.npz"), **out)
 
 
+def _reference_functions(names, namespace):
+    """The reference's training script cannot be imported (absent in-repo modules).  Its pure-torch helper
+    functions can still be RUN: parse the script as text, take the FunctionDef nodes asked for and exec only those in a
+    namespace we provide.  Build container only; nothing of the source is stored -- the outputs are."""
+    import ast
+    tree = ast.parse(open(os.path.join(REF, "train_ours_2D.py")).read())
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(n.name for n in picked) == sorted(names)
+    exec(compile(ast.Module(body=picked, type_ignores=[]), "train_ours_2D.py", "exec"), namespace)
+    return [namespace[n] for n in names]
+
+
+def gen_train_plumbing():
+    """H13 / H14 pins: the reference's own `mix_loss` (train_ours_2D.py:198-216) and `generate_mask` (:91-101) executed on
+    seeded inputs.  `losses.DiceLoss_bcp` is absent upstream, so the build's definition (oracle.train_step.dice_loss_bcp) is
+    injected as `dice_loss`: the pin covers the weighting / masking / cross-entropy plumbing around it (a PARTIAL pin, said so
+    in DESIGN.md).  generate_mask draws its box from numpy's RNG: seeded here, the offsets are stored with the masks."""
+    import torch.nn.functional as F
+    from oracle import train_step as ots
+
+    def dice_loss(soft, target, mask):                       # losses.DiceLoss_bcp(n_classes=4)(soft, target[N,1,H,W], mask[N,1,H,W])
+        return ots.dice_loss_bcp(soft, target.squeeze(1), mask.squeeze(1), soft.shape[1])
+
+    ns = dict(torch=torch, nn=nn, F=F, np=np, dice_loss=dice_loss)
+    mix_loss, generate_mask = _reference_functions(["mix_loss", "generate_mask"], ns)
+    g = torch.Generator().manual_seed(2024)
+    N, C, H, W = 3, 4, 24, 36
+    out = {}
+    logits = torch.randn(N, C, H, W, generator=g) * 2
+    img_l = torch.randint(0, C, (N, H, W), generator=g)
+    patch_l = torch.randint(0, C, (N, H, W), generator=g)
+    np.random.seed(7)
+    mask, loss_mask = generate_mask(torch.zeros(N, 1, H, W))
+    ys, xs = np.where(mask.numpy() == 0)
+    out.update(logits=_np(logits), img_l=img_l.numpy(), patch_l=patch_l.numpy(), mask=mask.numpy(), loss_mask=loss_mask.numpy(),
+               box=np.array([ys.min(), xs.min(), ys.max() - ys.min() + 1, xs.max() - xs.min() + 1]))
+    for tag, kw in (("lab", dict(u_weight=0.5)), ("unlab", dict(u_weight=0.5, unlab=True)), ("w", dict(l_weight=0.7, u_weight=0.3))):
+        lg = logits.clone().double().requires_grad_(True)
+        li, lp, tot = mix_loss(lg, img_l, patch_l, loss_mask.double(), **kw)
+        tot.backward()
+        out["%s_losses" % tag] = np.array([float(li), float(lp), float(tot)])
+        out["%s_dlogits" % tag] = _np(lg.grad)
+    np.savez_compressed(os.path.join(OUT, "train_plumbing.npz"), **out)
+    print("train_plumbing.npz: mix_loss x3 weightings, generate_mask box", out["box"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -402,6 +448,7 @@ def main():
     gen_2d_variants(ref)
     gen_3d(ref)
     gen_filter_dropout(ref)
+    gen_train_plumbing()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

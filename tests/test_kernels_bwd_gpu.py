@@ -181,6 +181,46 @@ def test_losses_vs_oracle():
     assert torch.equal(loss_b.view(torch.int32), loss.view(torch.int32))
 
 
+def test_mix_loss_and_box_kernels_against_the_reference_functions(golden_dir):
+    """chap_mix_loss_fwd/bwd, chap_box_mask against outputs of the reference's own mix_loss / generate_mask
+    (tests/golden/train_plumbing.npz, see tests/test_oracle_golden.py)."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(golden_dir, "train_plumbing.npz"))
+    logits = torch.from_numpy(z["logits"]).to(DEV)
+    img_l, patch_l = torch.from_numpy(z["img_l"]).to(DEV), torch.from_numpy(z["patch_l"]).to(DEV)
+    N, _, H, W = logits.shape
+    box = torch.tensor([int(v) for v in z["box"]], dtype=torch.int32, device=DEV)
+    lm = torch.empty(N, H, W, dtype=torch.int64, device=DEV)
+    ops.box_mask(lm, box)
+    assert np.array_equal(lm.cpu().numpy(), z["loss_mask"])
+    for tag, (wa, wb) in (("lab", (1.0, 0.5)), ("unlab", (0.5, 1.0)), ("w", (0.7, 0.3))):      # (image_weight, patch_weight), train_ours_2D.py:201-204
+        loss, acc = ops.mix_loss_fwd(logits, img_l, patch_l, lm, wa, wb)
+        dl = torch.empty_like(logits)
+        ops.mix_loss_bwd(logits, img_l, patch_l, lm, wa, wb, acc, dl)
+        assert relerr(loss.cpu(), torch.from_numpy(z["%s_losses" % tag]).float()) < 1e-5, tag
+        assert relerr(dl, torch.from_numpy(z["%s_dlogits" % tag])) < 1e-4, tag
+
+
+def test_largest_cc_tie_goes_to_the_component_met_first_in_raster_order():
+    """get_ACDC_2DLargestCC (train_ours_2D.py:134-136) keeps np.argmax(np.bincount(labels.flat)[1:]) + 1: on equal sizes the
+    FIRST label, and skimage / scipy number components in raster order of their first pixel."""
+    lab = torch.zeros(3, 16, 24, dtype=torch.int64)
+    lab[0, 2:5, 3:6] = 1; lab[0, 9:12, 15:18] = 1                  # two 3x3 squares of class 1: the upper-left one is met first
+    lab[1, 10:12, 1:4] = 2; lab[1, 2:4, 18:21] = 2                 # two 2x3 blocks of class 2: the one whose first pixel comes first (row 2) wins
+    lab[1, 6, 0:5] = 3; lab[1, 6, 8:13] = 3; lab[1, 7, 20:24] = 3  # class 3: two 5-pixel runs on one row (left wins) and a smaller one
+    lab[2, 5:9, 5:9] = 1; lab[2, 0:4, 12:16] = 1; lab[2, 12, 2] = 1  # 4x4 squares: the one starting in row 0 wins although it lies to the right
+    ref = ots.largest_cc(lab, 4)
+    got = ops.largest_cc(lab.to(DEV), 4).cpu()
+    assert torch.equal(got, ref)
+    assert got[0, 3, 4] == 1 and got[0, 10, 16] == 0 and got[1, 2, 19] == 2 and got[1, 10, 2] == 0
+    assert got[1, 6, 2] == 3 and got[1, 6, 10] == 0 and got[2, 1, 13] == 1 and got[2, 6, 6] == 0
+    vol = torch.zeros(1, 6, 8, 8, dtype=torch.int64)                # 3D (26-connectivity): two 2x2x2 cubes, the one in the lower z wins
+    vol[0, 0:2, 4:6, 4:6] = 1; vol[0, 3:5, 0:2, 0:2] = 1
+    got3 = ops.largest_cc(vol.to(DEV), 2).cpu()
+    assert torch.equal(got3, ots.largest_cc(vol, 2)) and got3[0, 0, 4, 4] == 1 and got3[0, 3, 0, 0] == 0
+
+
 def test_lcc_diffmask_vat_helpers_sgd():
     g = torch.Generator().manual_seed(16)
     N, H, W = 5, 64, 96

@@ -173,3 +173,26 @@ def test_dualdecoder2d_plus_and_same_variants(golden_dir):
         assert _relerr(dx, g[dt + "_train64_dx"]) < 1e-5
         for i, n in enumerate(g["grad_pick_names"]):
             assert _relerr(sd64[str(n)].grad, g["%s_train64_grad_pick%d" % (dt, i)]) < 1e-5, (dt, n)
+
+
+def test_oracle_mix_loss_and_generate_mask_against_the_reference_functions(golden_dir):
+    """H13 / H14: tests/golden/train_plumbing.npz holds outputs of the reference's OWN mix_loss / generate_mask
+    (train_ours_2D.py:198-216, 91-101; executed from the script's source in the build container by oracle/gen_golden.py
+    with the build's DiceLoss_bcp injected -- a partial pin: the Dice term itself is the build's definition)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import train_step as ots
+    z = np.load(os.path.join(golden_dir, "train_plumbing.npz"))
+    logits, img_l, patch_l = torch.from_numpy(z["logits"]), torch.from_numpy(z["img_l"]), torch.from_numpy(z["patch_l"])
+    y0, x0, bh, bw = (int(v) for v in z["box"])
+    N, _, H, W = logits.shape
+    assert (bh, bw) == (int(H * 2 / 3), int(W * 2 / 3))
+    mask, loss_mask = ots.box_masks(N, H, W, y0, x0)
+    assert np.array_equal(mask.long().numpy(), z["mask"]) and np.array_equal(loss_mask.long().numpy(), z["loss_mask"])
+    for tag, kw in (("lab", dict(u_weight=0.5)), ("unlab", dict(u_weight=0.5, unlab=True)), ("w", dict(l_weight=0.7, u_weight=0.3))):
+        lg = logits.clone().double().requires_grad_(True)
+        li, lp, tot = ots.mix_loss(lg, img_l, patch_l, loss_mask.double(), **kw)
+        tot.backward()
+        assert np.allclose(np.array([float(li), float(lp), float(tot)]), z["%s_losses" % tag], rtol=1e-9, atol=1e-12)
+        assert np.allclose(lg.grad.numpy(), z["%s_dlogits" % tag], rtol=1e-5, atol=1e-9)
