@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--trace-plan", default=None)
     ap.add_argument("--vat-iters", type=int, default=1)
+    ap.add_argument("--eager", action="store_true", help="time plain launch loops instead of a captured graph (rocprofv3 --pmc passes)")
     args = ap.parse_args()
 
     from chap_amd import _lib as L
@@ -192,10 +193,17 @@ def main():
         torch.cuda.synchronize()
         # the timing loop is a captured HIP graph of `reps` back-to-back launches: the Python / ctypes launch cost
         # (20-40 us per call) would otherwise bound every kernel shorter than that
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for _ in range(args.reps):
-                fn()
+        class _Eager:
+            def replay(self):
+                for _ in range(args.reps):
+                    fn()
+        if args.eager:
+            g = _Eager()
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(args.reps):
+                    fn()
         g.replay()
         torch.cuda.synchronize()
         if args.trace_plan:
