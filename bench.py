@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--dp-overlap", action="store_true", help="data-parallel: all-reduce bucket 0 beside the VAT chain (four-graph replay) instead of "
                     "folding the buckets and all-reducing once at the end (default: measured faster, see DESIGN.md section 6)")
     ap.add_argument("--master-port", type=int, default=29531)
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=VALUE", help="override a ChapStep argument (experiments), e.g. --set vat_early=0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=5)       # ~13 s of CPU work at 2D config 1 (9.4 vol/s on 16 cores)
     return ap.parse_args()
@@ -287,12 +288,16 @@ def main():
     H = args.size
     sp = tuple(args.size3d) if d3 else (H, H)
     torch.manual_seed(1337)
+    extra = {}
+    for kv in args.set:
+        k, v = kv.split("=", 1)
+        extra[k] = json.loads(v) if v[:1] in "0123456789-[{tfn\"" else v
     if d3:
         model = DualDecoder3d(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True).to(dev).train().set_compute_dtype(dtype)
-        step = ChapStep(model, dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters, num_classes=2), world_size=world)
+        step = ChapStep(model, dict(dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters, num_classes=2), **extra), world_size=world)
     else:
         model = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(dev).train().set_compute_dtype(dtype)
-        step = ChapStep(model, dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters), world_size=world)
+        step = ChapStep(model, dict(dict(batch_size=B, labeled_bs=B // 2, vat_iters=args.vat_iters), **extra), world_size=world)
     if dist is not None:
         from chap_amd.parallel import DataParallelSync
         step.grad_sync = DataParallelSync(step.grad_both, dist, overlap=args.dp_overlap)

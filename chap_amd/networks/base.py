@@ -197,17 +197,25 @@ class ChapNet(nn.Module):
         for (name, p), o in zip(self._param_list(), self._offsets):
             p.grad = new_flat_grad[o:o + p.numel()].view(p.shape)
 
-    def backward_saved(self, out, dlogits, grad_buffer):
+    def prepare_weights(self):
+        """Re-pack the weights now, on the current stream, if an optimizer step has changed them.  A caller that is about to
+        run forward passes of this model on SEVERAL streams at once must do this first: otherwise the first pass re-packs on
+        its stream while the others already read the packed copies."""
+        self._ensure_flat()
+        self._exec._ensure_packed(self.compute_dtype, self._exec._sd())
+
+    def backward_saved(self, out, dlogits, grad_buffer=None, need_wgrad=True, need_dx=False):
         """Run the backward pass of the forward that produced `out` (a logits tensor of this network) directly -- not through
-        torch.autograd -- accumulating the parameter gradients of sum_h <logits_h, dlogits_h> into `grad_buffer` (a flat
-        buffer with this model's layout).  May be called several times on one forward (the saved state is kept until
-        release_saved): the backward pass is linear in dlogits, so the gradients of the parts of a loss can be taken apart
-        (GradSim: labeled vs unlabeled part of the BCP loss)."""
+        torch.autograd, on the CURRENT stream (autograd would run it on the forward's stream) -- accumulating the parameter
+        gradients of sum_h <logits_h, dlogits_h> into `grad_buffer` (a flat buffer with this model's layout; None = the
+        model's own) and / or returning the input gradient.  May be called several times on one forward (the saved state is
+        kept until release_saved): the backward pass is linear in dlogits, so the gradients of the parts of a loss can be
+        taken apart (GradSim: labeled vs unlabeled part of the BCP loss)."""
         ctx = out.grad_fn
         if ctx is None or getattr(ctx, "S", None) is None:
             raise RuntimeError("chap_amd: backward_saved needs the output of a forward pass that saved its state")
         dl = [None if g is None else g.contiguous() for g in dlogits]
-        self._exec.backward(ctx.S, dl, dtype=self.compute_dtype, need_wgrad=True, need_dx=False, grad_buffer=grad_buffer)
+        return self._exec.backward(ctx.S, dl, dtype=self.compute_dtype, need_wgrad=need_wgrad, need_dx=need_dx, grad_buffer=grad_buffer)
 
     def release_saved(self, out):
         ctx = out.grad_fn

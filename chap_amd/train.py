@@ -67,12 +67,12 @@ class VAT2d:
     def __init__(self, xi=10.0, epi=6.0, num_classes=4, ip=1, sign=False):
         self.xi, self.epi, self.num_classes, self.ip, self.sign = xi, epi, num_classes, ip, sign
 
-    def __call__(self, model, x, soft1, soft2, mask, losstype="kl", weight_dev=None, inject=None, accumulate_grad=True, grad_buffer=None,
-                 weight=1.0):
-        if losstype not in ops.DIST_MODES:
-            raise ValueError("chap_amd VAT2d: adv_losstype=%r (--adv_losstype {kl,dice}, train_ours_2D.py:515)" % (losstype,))
+    def begin(self, model, x, U, inject=None):
+        """The part of the VAT computation that does NOT depend on pass A: the initial direction d (U(-.5,.5), per-sample L2
+        normalised) and the forward pass of the first power iteration on x + xi * d.  ChapStep runs it on a stream of its own
+        BESIDE pass A (the two forwards only meet in the distance kernel), which takes one forward pass off the critical chain
+        of the iteration.  Returns the state for finish()."""
         inject = inject or {}
-        U = soft1.shape[0]
         x = x[-U:].contiguous()                 # "perturb the last U samples" (SURVEY.md section 3.1 note)
         d = torch.empty_like(x)
         if inject.get("d0") is not None:
@@ -81,15 +81,31 @@ class VAT2d:
             ops.rand_uniform(d, model._rng.next_seed(), -0.5, 0.5, seed_dev=model._rng.seed_dev)
             ops.l2_normalize(d, d)
         xh = torch.empty_like(x).requires_grad_(True)
-        for it in range(self.ip):
+        first = None
+        if self.ip > 0:
             ops.perturb(x, d, xh, self.xi)
             with model.frozen():
-                l1, l2 = model(xh, update_stats=False, drop_masks=inject.get("drop_V%d" % it))
+                first = model(xh, update_stats=False, drop_masks=inject.get("drop_V0"))
+        return dict(x=x, d=d, xh=xh, first=first, inject=inject)
+
+    def finish(self, model, st, soft1, soft2, mask, losstype="kl", weight_dev=None, accumulate_grad=True, grad_buffer=None, weight=1.0):
+        if losstype not in ops.DIST_MODES:
+            raise ValueError("chap_amd VAT2d: adv_losstype=%r (--adv_losstype {kl,dice}, train_ours_2D.py:515)" % (losstype,))
+        x, d, xh, inject = st["x"], st["d"], st["xh"], st["inject"]
+        for it in range(self.ip):
+            if it == 0:
+                l1, l2 = st["first"]
+            else:
+                ops.perturb(x, d, xh, self.xi)
+                with model.frozen():
+                    l1, l2 = model(xh, update_stats=False, drop_masks=inject.get("drop_V%d" % it))
             g1, g2 = torch.empty_like(l1), torch.empty_like(l2)
             ops.kl_fwd_bwd((l1, l2), (soft1, soft2), None, (g1, g2), mode=losstype)
-            xh.grad = None
-            torch.autograd.backward([l1, l2], [g1, g2])
-            ops.l2_normalize(xh.grad, d)
+            # d(distance)/d(x) only (the weights are frozen: no weight-gradient kernels), on the CURRENT stream whatever stream the
+            # forward ran on (torch.autograd would run the node on the forward's stream)
+            dx = model.backward_saved(l1, [g1, g2], need_wgrad=False, need_dx=True)
+            model.release_saved(l1)
+            ops.l2_normalize(dx, d)
         xa = torch.empty_like(x)
         m = None if mask is None else mask.reshape(x.shape)
         alpha = self.epi / math.sqrt(x[0].numel()) if self.sign else self.epi
@@ -105,6 +121,13 @@ class VAT2d:
                 l1, l2 = model(xa, update_stats=False, drop_masks=inject.get("drop_VF"))
             ops.kl_fwd_bwd((l1, l2), (soft1, soft2), loss, mode=losstype)
         return loss
+
+    def __call__(self, model, x, soft1, soft2, mask, losstype="kl", weight_dev=None, inject=None, accumulate_grad=True, grad_buffer=None,
+                 weight=1.0):
+        if losstype not in ops.DIST_MODES:
+            raise ValueError("chap_amd VAT2d: adv_losstype=%r (--adv_losstype {kl,dice}, train_ours_2D.py:515)" % (losstype,))
+        st = self.begin(model, x, soft1.shape[0], inject)
+        return self.finish(model, st, soft1, soft2, mask, losstype, weight_dev, accumulate_grad, grad_buffer, weight)
 
 
 class GradSim:
@@ -199,6 +222,7 @@ class ChapStep:
         # stays on the origin stream, where the executor may fork its second decoder, and the short one (pass B)
         # goes to the side stream with its decoders back to back.
         self._d2 = torch.cuda.Stream(device=dev) if self.concurrent else None
+        self._pre = torch.cuda.Stream(device=dev) if self.concurrent else None      # the VAT pre-pass beside pass A
 
     # ------------------------------------------------------------------ host-side schedule values
     def prepare(self, box_yx=None):
@@ -317,10 +341,25 @@ class ChapStep:
         ctx = dict(inject=inject, volume_batch=volume_batch, lsub=lsub, usub=usub,
                    img_a=volume_batch[:lsub], img_b=volume_batch[lsub:lbs], uimg_a=volume_batch[lbs:lbs + usub], uimg_b=volume_batch[lbs + usub:],
                    lab_a=label_batch[:lsub], lab_b=label_batch[lsub:lbs], uimg_ab=volume_batch[lbs:])
+        # ---- the first VAT power-iteration forward (x + xi * d) needs nothing from pass A: it runs beside it on its own stream
+        main = torch.cuda.current_stream()
+        # (`vat_early`, default off: 2D 7.78 -> 7.58 ms, 3D 19.48 -> 19.12 ms per step, but with it two identical runs are no longer
+        #  bitwise equal in every process state -- tools/lab/nondet_probe5.py -- and reproducibility is what the parity gates test)
+        pre = self._pre if (self.concurrent and a["adv_noise"] and a.get("vat_early", False)) else None
+        model.prepare_weights()                  # before the streams fork: every pass of the iteration reads the same packed copies
+        if a["adv_noise"]:
+            if pre is not None:
+                pre.wait_stream(main)
+                with torch.cuda.stream(pre):
+                    ctx["vat_state"] = self.adv_loss.begin(model, volume_batch, B - lbs, inject)
+            else:
+                ctx["vat_state"] = self.adv_loss.begin(model, volume_batch, B - lbs, inject)
         # ---- pass A: pseudo labels from both decoders (no grad), train_ours_2D.py:314-330
         with torch.no_grad():
             pre_ab1, pre_ab2 = model(ctx["uimg_ab"], drop_masks=inject.get("drop_A"))
             soft1, soft2, pseudo1, pseudo2, knowledge = ops.pseudo_block(pre_ab1, pre_ab2)
+        if pre is not None:
+            main.wait_stream(pre)
         ctx.update(outputs_soft1=soft1, outputs_soft2=soft2, pseudo_outputs1=pseudo1, pseudo_outputs2=pseudo2, knowledge=knowledge)
         # ---- the VAT branch (:368-375) depends only on pass A: it and pass B run side by side on two streams and
         #      accumulate their parameter gradients into separate buckets (VAT: the second one)
@@ -395,8 +434,8 @@ class ChapStep:
         a = self.args
         if not a["adv_noise"]:
             return torch.zeros(1, dtype=torch.float32, device=ctx["volume_batch"].device)
-        return self.adv_loss(self.model, ctx["volume_batch"], ctx["outputs_soft1"], ctx["outputs_soft2"], ctx["diff_mask"], a["adv_losstype"],
-                             weight_dev=self.cw_dev, inject=ctx["inject"], grad_buffer=self.grad2)
+        return self.adv_loss.finish(self.model, ctx["vat_state"], ctx["outputs_soft1"], ctx["outputs_soft2"], ctx["diff_mask"], a["adv_losstype"],
+                                    weight_dev=self.cw_dev, grad_buffer=self.grad2)
 
     def _fp_branch(self, uimg_ab, pseudo1, pseudo2, inject, capturing):
         """"2) fp" of the loop (train_ours_2D.py:359-365, default off): both decoders on the channel-perturbed features
