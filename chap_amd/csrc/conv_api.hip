@@ -10,9 +10,12 @@ typedef int (*conv_launch_fn)(const chap_conv_params*, int, int, int, hipStream_
 struct conv_blocking { int KC, GPT, NP, STEPS, nchunks, ntiles; };
 
 // K-side geometry shared by the packer and the kernel: Ck = GEMM-K channels, taps = kernel taps.
-static conv_blocking blocking_for(int Ck, int taps, int Cout_logical) {
+static conv_blocking blocking_for(int Ck, int taps, int Cout_logical, int dtype) {
     conv_blocking b;
     b.KC = (Ck >= 32 && Ck % 32 == 0) ? 32 : 16;      // e.g. 16 + 32 concatenated channels (unet_3D) walk in chunks of 16
+    // (tried in round 2: 64-channel chunks for the deep 2D layers, to halve the chain of dependent chunk round trips of a tile --
+    //  weights then stream from L2 to keep two blocks per CU; single layers -0..6 %, the whole 2D iteration 7.83 -> 8.26 ms: dropped)
+    (void)dtype;
     // 3D 3x3x3 with <= 32 input channels (the large-volume levels): chunks of 16 keep the 6x6x18 halo brick at 41 KB
     // (two buffers), which leaves LDS for the staged weights and registers for a pipelined tap loop: 32->16 at
     // 80x112x112 runs 1.9x faster than with KC = 32 (weights streamed from L2 inside the tap loop)
@@ -49,7 +52,7 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     if (!p->out_planar) CHAP_CHECK_ARG(p->out_ld % 4 == 0 && p->out_coff % 4 == 0, "chap_conv_fwd: out_ld/out_coff must be multiples of 4");
     const int Ck = p->combine == 0 ? p->src[0].C + (p->nsrc > 1 ? p->src[1].C : 0) : p->src[0].C;
     const int taps = p->ksize * p->ksize * (p->dims == 3 ? p->ksize : 1);
-    conv_blocking b = blocking_for(Ck, taps, p->Cout);
+    conv_blocking b = blocking_for(Ck, taps, p->Cout, p->dtype);
     CHAP_CHECK_ARG(Ck % b.KC == 0, "chap_conv_fwd: K channels %d not a multiple of %d", Ck, b.KC);
     // geometry family
     const bool d3 = p->dims == 3;
@@ -181,7 +184,7 @@ extern "C" int chap_pack_describe(const chap_pack_params* p, chap_pack_entry* e)
     pack_geom g;
     int r = pack_geometry(p, &g);
     if (r) return r;
-    conv_blocking b = blocking_for(g.Ck, g.ctaps, g.Cn_logical);
+    conv_blocking b = blocking_for(g.Ck, g.ctaps, g.Cn_logical, p->dtype);
     CHAP_CHECK_ARG(g.Ck % b.KC == 0, "chap_pack_describe: K channels %d not a multiple of %d", g.Ck, b.KC);
     e->w = p->w; e->out = p->out; e->kind = p->kind; e->Cin = p->Cin; e->Cout = p->Cout; e->taps = p->taps; e->dtype = p->dtype;
     e->KC = b.KC; e->GPT = b.GPT; e->NP = b.NP; e->STEPS = b.STEPS; e->nchunks = b.nchunks; e->ntiles = b.ntiles;
@@ -202,7 +205,7 @@ extern "C" int chap_pack_multi(const chap_pack_entry* entries_dev, int32_t n, in
 extern "C" size_t chap_pack_size(const chap_pack_params* p) {
     pack_geom g;
     if (!p || pack_geometry(p, &g)) return 0;
-    conv_blocking b = blocking_for(g.Ck, g.ctaps, g.Cn_logical);
+    conv_blocking b = blocking_for(g.Ck, g.ctaps, g.Cn_logical, p->dtype);
     return (size_t)b.nchunks * b.STEPS * b.ntiles * 64 * 8 * (p->dtype == CHAP_BF16 ? 2 : 4);
 }
 
@@ -212,7 +215,7 @@ extern "C" int chap_pack_weights(const chap_pack_params* p, void* stream) {
     int r = pack_geometry(p, &g);
     if (r) return r;
     CHAP_CHECK_ARG(g.Ck % 16 == 0, "chap_pack_weights: K channels %d must be a multiple of 16", g.Ck);
-    conv_blocking b = blocking_for(g.Ck, g.ctaps, g.Cn_logical);
+    conv_blocking b = blocking_for(g.Ck, g.ctaps, g.Cn_logical, p->dtype);
     CHAP_CHECK_ARG(g.Ck % b.KC == 0, "chap_pack_weights: K channels %d not a multiple of %d", g.Ck, b.KC);
     const long total = (long)b.nchunks * b.STEPS * b.ntiles * 64;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

@@ -235,9 +235,23 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const chap_bn_finalize
     const int nsub = P.Clog / P.C;
     const float* st = P.stats + CHAP_STATS_HDR;
     double s = 0.0, q = 0.0;
-    for (int b = lane; b < nslots; b += 64) {
-        const float* row = st + (long)b * 2 * P.Clog;
-        for (int k = 0; k < nsub; ++k) { s += (double)row[k * P.C + c]; q += (double)row[P.Clog + k * P.C + c]; }
+    // a lane's slots are lane, lane + 64, ...: at most CHAP_STATS_MAX_SLOTS / 64 = 16 of them.  All loads of a batch are issued
+    // before the first add (the kernel is pure latency: one dependent load per iteration made it 6.7 us), the adds keep the
+    // fixed order b = lane, lane + 64, ...
+    constexpr int NB = CHAP_STATS_MAX_SLOTS / 64;
+    for (int k = 0; k < nsub; ++k) {
+        float vs[NB], vq[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int b = lane + 64 * i;
+            const float* row = st + (long)(b < nslots ? b : 0) * 2 * P.Clog + k * P.C + c;
+            vs[i] = row[0]; vq[i] = row[P.Clog];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const bool ok = lane + 64 * i < nslots;
+            s += ok ? (double)vs[i] : 0.0; q += ok ? (double)vq[i] : 0.0;
+        }
     }
     s = wave_sum_f64(s); q = wave_sum_f64(q);
     if (lane != 0) return;
@@ -681,7 +695,15 @@ __global__ __launch_bounds__(256) void act_bwd_sum_kernel(float* sums, int nbloc
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= 2 * C) return;
     double t = 0.0;
-    for (int b = lane; b < nblocks; b += 64) t += (double)sums[(long)(1 + b) * 2 * C + i];
+    constexpr int NB = CHAP_ACT_BWD_SLOTS / 64;                  // all of a lane's loads in flight at once, adds in the fixed order
+    float vv[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int b = lane + 64 * k;
+        vv[k] = sums[(long)(1 + (b < nblocks ? b : 0)) * 2 * C + i];
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) t += (lane + 64 * k < nblocks) ? (double)vv[k] : 0.0;
     t = wave_sum_f64(t);
     if (lane != 0) return;
     const float v = (float)t;
