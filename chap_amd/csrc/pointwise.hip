@@ -726,7 +726,9 @@ static int act_bwd_blocks(const chap_act_bwd_params* p) {
     long b = (npix + ppb - 1) / ppb;
     // 4 blocks per CU: swept on the whole iteration (512 / 1024 / 2048 / 4096 / 8192 blocks -> 7.59 / 7.39 / 7.58 / 8.07 / 8.01 ms per
     // 2D step): more blocks only add atomics and take CUs from the kernels of the other streams
-    return (int)(b < CHAP_ACT_BWD_SLOTS ? b : CHAP_ACT_BWD_SLOTS);          // one partial row per block
+    static long cap = 0;
+    if (!cap) { const char* e = getenv("CHAP_ACTBWD_BLOCKS"); cap = (e && atol(e) > 0 && atol(e) <= CHAP_ACT_BWD_SLOTS) ? atol(e) : CHAP_ACT_BWD_SLOTS; }      // lab knob
+    return (int)(b < cap ? b : cap);          // one partial row per block
 }
 extern "C" int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream) {
     int r = act_bwd_check(p); if (r) return r;
