@@ -266,7 +266,8 @@ def iteration(sd, moms, volume_batch, label_batch, box_yx, iter_num, lr, args=No
         # "2) fp" (train_ours_2D.py:359-365): both decoders on cat(features, channel-perturbed features of the second half).
         # Upstream compares these 1.5 U logits with the U pseudo labels (a shape error) and takes the scores from the absent
         # grad.GradSim; here every output row is paired with its own sample's pseudo label -- cat(pseudo, pseudo[U/2:]) --
-        # and the scores are an input (all-zero scores = the Dropout2d pair of FilterDropout.py:71-73).  PARITY UNPINNED.
+        # and the scores are either injected (`sim_score`; all-zero = the Dropout2d pair of FilterDropout.py:71-73) or the running
+        # GradSim state (`gradsim`, restated below from the call sites alone).  PARITY UNPINNED.
         from . import filter_dropout as ofd
         U = uimg_ab.shape[0]
         ctx = nets.Ctx(True, inject.get("drop_FP"), True)
