@@ -252,17 +252,18 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // scale/shift of the 8 channels a thread stages, held in registers (per K-chunk; they do not depend on the tile)
 template <bool ADD2> struct aff_regs { f32x2 a[4], b[4], a2[ADD2 ? 4 : 1], b2[ADD2 ? 4 : 1]; };
 
-template <int KC, bool ADD2, bool ONE = false>
+// AFFC: capacity of the cache per source (scale | shift halves of AFFC / 2 channels each); the weight-gradient bricks use a small one
+template <int KC, bool ADD2, bool ONE = false, int AFFC = CONV_MAX_AFFINE_C>
 __device__ __forceinline__ void load_aff(aff_regs<ADD2>& A, const float* aff, int c8, int C0, int chunk, bool lanesel) {
     const int cb = chunk * KC;
     const bool second = (ADD2 || ONE) ? false : (lanesel ? (cb + c8 >= C0) : (cb >= C0));
-    const float* af = aff + (second ? CONV_MAX_AFFINE_C + cb - C0 : cb) + c8;
+    const float* af = aff + (second ? AFFC + cb - C0 : cb) + c8;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { A.a[k] = *(const f32x2*)(af + 2 * k); A.b[k] = *(const f32x2*)(af + CONV_MAX_AFFINE_C / 2 + 2 * k); }
+    for (int k = 0; k < 4; ++k) { A.a[k] = *(const f32x2*)(af + 2 * k); A.b[k] = *(const f32x2*)(af + AFFC / 2 + 2 * k); }
     if (ADD2) {
-        const float* af2 = aff + CONV_MAX_AFFINE_C + cb + c8;
+        const float* af2 = aff + AFFC + cb + c8;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { A.a2[k] = *(const f32x2*)(af2 + 2 * k); A.b2[k] = *(const f32x2*)(af2 + CONV_MAX_AFFINE_C / 2 + 2 * k); }
+        for (int k = 0; k < 4; ++k) { A.a2[k] = *(const f32x2*)(af2 + 2 * k); A.b2[k] = *(const f32x2*)(af2 + AFFC / 2 + 2 * k); }
     }
 }
 
@@ -285,7 +286,7 @@ __device__ __forceinline__ void keep8(float v[8], uint2 keep, float keep_scale) 
     }
 }
 
-template <typename T, int KC, bool ADD2, int UNITS, bool LANESEL, bool KEEPM, bool ONE>
+template <typename T, int KC, bool ADD2, int UNITS, bool LANESEL, bool KEEPM, bool ONE, int AFFC = CONV_MAX_AFFINE_C>
 __device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2, KEEPM>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
                                                  const float* aff, bool plain, int n, int chunk) {
     typedef typename frag<T>::type F;
@@ -304,7 +305,7 @@ __device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2,
     const bool hcm = second ? s1.has_cm : s0.has_cm;
     // scale/shift of this thread's 8 channels: 4 LDS reads per item are cheaper than 16 registers held across the MFMA loop
     aff_regs<ADD2> A;
-    load_aff<KC, ADD2, ONE>(A, aff, U.c8, s0.C, chunk, LANESEL);
+    load_aff<KC, ADD2, ONE, AFFC>(A, aff, U.c8, s0.C, chunk, LANESEL);
     f32x2 a[4], b[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { a[k] = A.a[k]; b[k] = A.b[k]; }
@@ -345,12 +346,12 @@ __device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2,
     }
 }
 
-template <typename T, int KC, bool ADD2, int UNITS, bool KEEPM, bool ONE = false>
+template <typename T, int KC, bool ADD2, int UNITS, bool KEEPM, bool ONE = false, int AFFC = CONV_MAX_AFFINE_C>
 __device__ __forceinline__ void halo_commit(const halo_regs<T, UNITS, ADD2, KEEPM>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
                                             const float* aff, bool plain, int n, int chunk, bool lanesel) {
-    if (ONE) halo_commit_impl<T, KC, ADD2, UNITS, false, KEEPM, true>(R, U, halo, s0, s0, aff, plain, n, chunk);
-    else if (!ADD2 && lanesel) halo_commit_impl<T, KC, ADD2, UNITS, true, KEEPM, false>(R, U, halo, s0, s1, aff, plain, n, chunk);
-    else halo_commit_impl<T, KC, ADD2, UNITS, false, KEEPM, false>(R, U, halo, s0, s1, aff, plain, n, chunk);
+    if (ONE) halo_commit_impl<T, KC, ADD2, UNITS, false, KEEPM, true, AFFC>(R, U, halo, s0, s0, aff, plain, n, chunk);
+    else if (!ADD2 && lanesel) halo_commit_impl<T, KC, ADD2, UNITS, true, KEEPM, false, AFFC>(R, U, halo, s0, s1, aff, plain, n, chunk);
+    else halo_commit_impl<T, KC, ADD2, UNITS, false, KEEPM, false, AFFC>(R, U, halo, s0, s1, aff, plain, n, chunk);
 }
 
 // tile index -> (n, z0, y0, x0); tiles_z = number of tile layers along D (D itself when the tile is one plane)

@@ -2,10 +2,10 @@
 #include <cstdlib>
 #include "common.h"
 
-int chap_wgrad_launch_bf16(const chap_wgrad_params* p, int KC, float* ws, float* ws_db, int nsplit, int Ca, int Cb, hipStream_t s);
-int chap_wgrad_launch_f32(const chap_wgrad_params* p, int KC, float* ws, float* ws_db, int nsplit, int Ca, int Cb, hipStream_t s);
+int chap_wgrad_launch_bf16(const chap_wgrad_params* p, int KC, int brick, float* ws, float* ws_db, int nsplit, int Ca, int Cb, hipStream_t s);
+int chap_wgrad_launch_f32(const chap_wgrad_params* p, int KC, int brick, float* ws, float* ws_db, int nsplit, int Ca, int Cb, hipStream_t s);
 
-struct wg_plan { int Ca, Cb, KC, taps, nsplit; long ntiles; size_t slab, bytes; };
+struct wg_plan { int Ca, Cb, KC, taps, nsplit, brick; long ntiles; size_t slab, bytes; };
 
 static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     CHAP_CHECK_ARG(p->na == 1 || p->na == 2, "chap_wgrad: na=%d", p->na);
@@ -14,11 +14,21 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     CHAP_CHECK_ARG(q->Ca % 16 == 0 && q->Cb % 8 == 0, "chap_wgrad: Ca=%d must be a multiple of 16, Cb=%d of 8", q->Ca, q->Cb);
     q->KC = (q->Ca >= 32 && q->Ca % 32 == 0) ? 32 : 16;
     if (p->dtype == CHAP_F32 && p->ksize == 2) q->KC = 16;      // fp32 k2 s2 halos: two buffers of 32 channels exceed the 160 KiB LDS
+    // 3D 3x3x3, bf16: 4 x 4 x 16 bricks with 16-channel A chunks once the volume has enough of them (the 1 x 4 x 16 slab stages
+    // 5.1 A-pixels per output pixel and pays a barrier + a prefetch round trip per 64 pixels; the brick 2.5 and one per 256)
+    q->brick = 0;
+    {
+        const char* eb = getenv("CHAP_WGRAD_BRICK");        // lab knob: 0 = slabs everywhere, N = bricks from N bricks up
+        const long min_bricks = eb ? atol(eb) : 512;
+        const long bricks = (long)p->N * cdiv(p->D, 4) * cdiv(p->H, 4) * cdiv(p->W, 16);
+        if (p->dims == 3 && p->ksize == 3 && p->stride == 1 && p->dtype == CHAP_BF16 && min_bricks > 0 && bricks >= min_bricks &&
+            p->a[0].C <= 64 && (p->na < 2 || p->a[1].C <= 64) && p->b.C <= 64) { q->brick = 1; q->KC = 16; }      // (<= 64 channels per source: the brick kernels' small scale/shift cache)
+    }
     CHAP_CHECK_ARG(q->Ca % q->KC == 0, "chap_wgrad: Ca=%d not a multiple of %d", q->Ca, q->KC);
     q->taps = p->ksize * p->ksize * (p->dims == 3 ? p->ksize : 1);
     const bool small_tile = (p->dims == 3 && p->ksize >= 2);   // 3D geometries use 4 x 16 tiles (MR = 1)
     const int TH = small_tile ? 4 : 8;
-    q->ntiles = (long)p->N * p->D * cdiv(p->H, TH) * cdiv(p->W, 16);
+    q->ntiles = (long)p->N * (q->brick ? cdiv(p->D, 4) : p->D) * cdiv(p->H, TH) * cdiv(p->W, 16);
     const long pairs = (long)(q->Ca / q->KC) * cdiv(q->Cb, q->Cb <= 16 ? 16 : 32);
     // Persistent, pipelined blocks.  What bounds the small-channel layers (most of the bytes) is memory-level parallelism --
     // a block keeps a few KB in flight -- so they take as many blocks as stay resident (LDS: 3 per CU with 16-channel chunks,
@@ -32,6 +42,7 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     const char* env = getenv("CHAP_WGRAD_BLOCKS");          // lab knob for those sweeps
     if (env && atol(env) > 0) target = atol(env);
     else if (p->ksize == 2) target = 256;
+    else if (q->brick) target = q->Cb <= 16 ? 512 : 256;      // 16-wide B tiles leave LDS for two bricks per CU (3D 16->16 at 112x112x80: 88 / 66 / 85 us with 256 / 512 / 768 blocks)
     else if (q->KC == 16) target = d3 ? 512 : 768;
     else if (!d3 && (p->na == 2 || q->Ca <= 32)) target = 512;
     long ns = target / pairs;
@@ -110,8 +121,8 @@ extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     float* ws = (float*)p->ws;
     float* ws_db = p->db ? ws + (size_t)q.nsplit * (q.slab / sizeof(float)) : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (p->dtype == CHAP_BF16) r = chap_wgrad_launch_bf16(p, q.KC, ws, ws_db, q.nsplit, q.Ca, q.Cb, s);
-    else if (p->dtype == CHAP_F32) r = chap_wgrad_launch_f32(p, q.KC, ws, ws_db, q.nsplit, q.Ca, q.Cb, s);
+    if (p->dtype == CHAP_BF16) r = chap_wgrad_launch_bf16(p, q.KC, q.brick, ws, ws_db, q.nsplit, q.Ca, q.Cb, s);
+    else if (p->dtype == CHAP_F32) r = chap_wgrad_launch_f32(p, q.KC, q.brick, ws, ws_db, q.nsplit, q.Ca, q.Cb, s);
     else { chap_set_error("chap_wgrad: dtype=%d", p->dtype); return CHAP_EINVAL; }
     if (r) return r;
     const long total = (long)q.taps * q.Ca * q.Cb;

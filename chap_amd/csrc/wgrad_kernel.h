@@ -14,13 +14,23 @@
 
 constexpr int WG_BN = 32;                       // B channels per block (16 for layers with <= 16 output channels)
 constexpr int WG_BDUMMY = 8;                    // elements behind each B tile: store target of threads without a B unit
-template <typename T> __host__ __device__ constexpr int wg_psb() { return sizeof(T) == 2 ? 40 : 36; }
+#ifndef CHAP_WGRAD_DEPTH
+#define CHAP_WGRAD_DEPTH 6
+#endif
+constexpr int WG_DEPTH = CHAP_WGRAD_DEPTH;      // A fragments (transposing LDS reads) in flight ahead of the MFMAs
+#ifndef CHAP_WGRAD_PSB16
+#define CHAP_WGRAD_PSB16 24
+#endif
+// LDS pixel stride of the B tile (elements): 32 (16) channels + padding for the transposing reads
+template <typename T, int BN = WG_BN> __host__ __device__ constexpr int wg_psb() { return sizeof(T) == 2 ? (BN == 16 ? CHAP_WGRAD_PSB16 : 40) : 36; }
+// scale/shift cache per source: the brick kernels run the 16..64-channel levels only and keep it small (LDS for a second block per CU)
+template <bool ZW> __host__ __device__ constexpr int wg_affc() { return ZW ? 128 : CONV_MAX_AFFINE_C; }
 
-template <typename T, int KS, int ST, bool D3, int KC, int MR, int BN = WG_BN>
+template <typename T, int KS, int ST, bool D3, int KC, int MR, int BN = WG_BN, bool ZW = false>
 __host__ __device__ constexpr size_t wgrad_lds_bytes() {
-    typedef conv_geom<KS, ST, D3, MR> G;
-    return 2 * ((size_t)G::HP * pix_stride<T, KC>() + HALO_DUMMY + (size_t)G::TH * G::TW * wg_psb<T>() + WG_BDUMMY) * sizeof(T)    // double-buffered A halo + B tile
-           + 3 * CONV_MAX_AFFINE_C * sizeof(float) + 4 * BN * sizeof(float);                               // affine caches (A0, A1, B), db partials
+    typedef conv_geom<KS, ST, D3, MR, ZW> G;
+    return 2 * ((size_t)G::HP * pix_stride<T, KC>() + HALO_DUMMY + (size_t)G::TD * G::TH * G::TW * wg_psb<T, BN>() + WG_BDUMMY) * sizeof(T)    // double-buffered A halo + B tile
+           + 3 * wg_affc<ZW>() * sizeof(float) + 4 * BN * sizeof(float);                                   // affine caches (A0, A1, B), db partials
 }
 
 __device__ __forceinline__ s16x4 lds_tr16(const bf16_t* p) {
@@ -33,30 +43,36 @@ __device__ __forceinline__ s16x4 lds_tr16(const bf16_t* p) {
 // of the 16-channel layers is a few KB, so one tile ahead (PD = 1) leaves the kernel latency-bound (0.9-1.5 TB/s); the ring
 // costs 12 VGPRs per extra tile there.  Loads are unconditional (the tile index is clamped: the tail re-reads the block's
 // last tile from L2) so that the compiler can count the waits instead of draining the queue (see halo_issue).
-template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int BN = WG_BN, int PD = 1>
+// ZW (3D, bf16): the tile is a TD x TH x 16 = 4 x 4 x 16 BRICK (conv_geom's z-per-wave geometry; here the waves split the
+// (tap, 16-row) pairs as always, the brick only changes which pixels a tile holds): its halo is 6 x 6 x 18 = 2.5 A-pixels per
+// output pixel where the 1 x 4 x 16 slab stages 3 x 6 x 18 = 5.1, and one barrier / prefetch round trip serves 256 pixels
+// instead of 64.
+template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int BN = WG_BN, int PD = 1, bool ZW = false>
 __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, float* __restrict__ ws, float* __restrict__ ws_db,
                                                     int nsplit, int Ca, int Cb) {
-    typedef conv_geom<KS, ST, D3, MR> G;
+    typedef conv_geom<KS, ST, D3, MR, ZW> G;
+    constexpr int TPX = G::TD * G::TH * G::TW;           // pixels per tile
+    static_assert(!ZW || (sizeof(T) == 2 && D3 && TPX % 32 == 0 && G::TH % 2 == 0), "brick tiles: 3D bf16 only");
     typedef typename frag<T>::type F;
-    constexpr int GPT = KC / 8, PS = pix_stride<T, KC>(), PSB = wg_psb<T>();
+    constexpr int GPT = KC / 8, PS = pix_stride<T, KC>(), PSB = wg_psb<T, BN>(), AFFC = wg_affc<ZW>();
     constexpr int KCT = KC / 16, NTB = BN / 16, CG = BN / 8;     // B: 16-channel MFMA tiles, 8-channel staging groups
     constexpr int PAIRS = G::NTAPS * KCT, MAXP = (PAIRS + 3) / 4;
-    constexpr int NKCH = G::TH * G::TW / 32;            // 32-pixel k-chunks per tile
+    constexpr int NKCH = TPX / 32;                      // 32-pixel k-chunks per tile (two rows of 16)
     constexpr int UNITS = (G::HP * GPT + 255) / 256;
-    constexpr int BUNITS = (G::TH * G::TW * CG + 255) / 256;
+    constexpr int BUNITS = (TPX * CG + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* halo0 = (T*)smem;
     T* halo1 = halo0 + (size_t)G::HP * PS + HALO_DUMMY;
     T* bt0 = halo1 + (size_t)G::HP * PS + HALO_DUMMY;
-    T* bt1 = bt0 + (size_t)G::TH * G::TW * PSB + WG_BDUMMY;
-    float* aff = (float*)(bt1 + (size_t)G::TH * G::TW * PSB + WG_BDUMMY);       // [A0 | A1 | B] x [scale | shift]
-    float* dbred = aff + 3 * CONV_MAX_AFFINE_C;
+    T* bt1 = bt0 + (size_t)TPX * PSB + WG_BDUMMY;
+    float* aff = (float*)(bt1 + (size_t)TPX * PSB + WG_BDUMMY);       // [A0 | A1 | B] x [scale | shift]
+    float* dbred = aff + 3 * AFFC;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int split = blockIdx.x, chunk = blockIdx.y, nb = blockIdx.z;
-    const int tiles_x = (P.W + G::TW - 1) / G::TW, tiles_y = (P.H + G::TH - 1) / G::TH;
-    const long ntiles = (long)P.N * P.D * tiles_y * tiles_x;
+    const int tiles_x = (P.W + G::TW - 1) / G::TW, tiles_y = (P.H + G::TH - 1) / G::TH, tiles_z = (P.D + G::TD - 1) / G::TD;
+    const long ntiles = (long)P.N * tiles_z * tiles_y * tiles_x;
     const long my_tiles = split < ntiles ? (ntiles - split + nsplit - 1) / nsplit : 0;
 
     const src_scalars s0 = make_scalars(P.a[0]);
@@ -70,7 +86,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
     unit_desc<UNITS> U;
     make_units<G, GPT, PS, UNITS>(U, P.IH, P.IW);
     const bool lanesel = !ADD2 && P.na > 1 && (P.a[0].C % KC) != 0;
-    int b_yx[BUNITS], b_rel[BUNITS], b_lds[BUNITS];     // B tile units: (row << 8 | col), pixel offset, LDS offset; channel = nb*32 + (tid % 4) * 8
+    int b_yx[BUNITS], b_rel[BUNITS], b_lds[BUNITS];     // B tile units: (plane << 16 | row << 8 | col), pixel offset, LDS offset; channel = nb*32 + (tid % 4) * 8
     const int bc8 = (threadIdx.x & (CG - 1)) * 8;
     const int cbB = nb * BN + bc8;
     const bool bchan_ok = cbB < Cb;
@@ -78,11 +94,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
     for (int j = 0; j < BUNITS; ++j) {
         const int u = threadIdx.x + 256 * j;
         const int pix = u / CG;
-        b_yx[j] = -1; b_rel[j] = 0; b_lds[j] = G::TH * G::TW * PSB;      // no such unit: loads the tile origin, stores to the dummy slot
-        if (pix < G::TH * G::TW) {
-            const int row = pix / G::TW, col = pix % G::TW;
-            b_yx[j] = (row << 8) | col;
-            b_rel[j] = row * P.W + col;
+        b_yx[j] = -1; b_rel[j] = 0; b_lds[j] = TPX * PSB;                // no such unit: loads the tile origin, stores to the dummy slot
+        if (pix < TPX) {
+            const int pz = pix / (G::TH * G::TW), row = (pix / G::TW) % G::TH, col = pix % G::TW;
+            b_yx[j] = (pz << 16) | (row << 8) | col;
+            b_rel[j] = (pz * P.H + row) * P.W + col;
             b_lds[j] = pix * PSB + bc8;
         }
     }
@@ -90,9 +106,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
     for (int s = 0; s < 3; ++s) {
         const chap_src_t& src = s == 2 ? P.b : P.a[s < P.na ? s : 0];
         const bool has = src.scale != nullptr;
-        for (int c = threadIdx.x; c < src.C && c < CONV_MAX_AFFINE_C / 2; c += 256) {
-            aff[s * CONV_MAX_AFFINE_C + c] = has ? src.scale[c] : 1.f;
-            aff[s * CONV_MAX_AFFINE_C + CONV_MAX_AFFINE_C / 2 + c] = has ? src.shift[c] : 0.f;
+        for (int c = threadIdx.x; c < src.C && c < AFFC / 2; c += 256) {
+            aff[s * AFFC + c] = has ? src.scale[c] : 1.f;
+            aff[s * AFFC + AFFC / 2 + c] = has ? src.shift[c] : 0.f;
         }
     }
 
@@ -116,9 +132,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
         halo_regs<T, UNITS, ADD2, !D3>& R = Q.R;
         F (&braw)[BUNITS] = Q.braw; uint2 (&bkeep)[BUNITS] = Q.bkeep; unsigned& bok = Q.bok;
         int n, z0, y0, x0;
-        tile_coords<G::TH, G::TW, 1>(tile, tiles_x, tiles_y, P.D, n, z0, y0, x0);
+        tile_coords<G::TH, G::TW, G::TD>(tile, tiles_x, tiles_y, tiles_z, n, z0, y0, x0);
         Q.n = n;
-        halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS>(R, U, s0, s1, P.ID, P.IH, P.IW, n, z0, y0, x0, chunk, lanesel);
+        halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW>(R, U, s0, s1, P.ID, P.IH, P.IW, n, z0, y0, x0, chunk, lanesel);
         const long gp0 = (((long)n * P.D + z0) * P.H + y0) * P.W + x0;
         const char* bb = (const char*)sb.ptr + (gp0 * sb.ld + sb.coff + cbB_safe) * (long)sizeof(T);
         const unsigned ldb = sb.ld * sizeof(T);
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
 #pragma unroll
         for (int j = 0; j < BUNITS; ++j) {
             const int d = b_yx[j];
-            const bool ok = d >= 0 && bchan_ok && y0 + (d >> 8) < P.H && x0 + (d & 255) < P.W;
+            const bool ok = d >= 0 && bchan_ok && (!ZW || z0 + (d >> 16) < P.D) && y0 + ((d >> 8) & 255) < P.H && x0 + (d & 255) < P.W;
             bok |= ok ? (1u << j) : 0u;
             r[j] = ok ? (unsigned)b_rel[j] : 0u;
         }
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
     auto commit = [&](const pre_t& Q, T* halo, T* bt) __attribute__((always_inline)) {
         const halo_regs<T, UNITS, ADD2, !D3>& R = Q.R;
         const F (&braw)[BUNITS] = Q.braw; const uint2 (&bkeep)[BUNITS] = Q.bkeep; const unsigned bok = Q.bok; const int n = Q.n;
-        halo_commit<T, KC, ADD2, UNITS, !D3>(R, U, halo, s0, s1, aff, plainA, n, chunk, lanesel);
+        halo_commit<T, KC, ADD2, UNITS, !D3, false, AFFC>(R, U, halo, s0, s1, aff, plainA, n, chunk, lanesel);
         f32x2 a[4], b[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { a[k] = ba[k]; b[k] = bb2[k]; }
@@ -201,42 +217,54 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
     __syncthreads();                                            // affine caches visible
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        ba[k] = *(const f32x2*)(aff + 2 * CONV_MAX_AFFINE_C + cbB_safe + 2 * k);
-        bb2[k] = *(const f32x2*)(aff + 2 * CONV_MAX_AFFINE_C + CONV_MAX_AFFINE_C / 2 + cbB_safe + 2 * k);
+        ba[k] = *(const f32x2*)(aff + 2 * AFFC + cbB_safe + 2 * k);
+        bb2[k] = *(const f32x2*)(aff + 2 * AFFC + AFFC / 2 + cbB_safe + 2 * k);
     }
     if (my_tiles > 0) commit(S[0], halo0, bt0);
     __syncthreads();
 
     auto compute = [&](const T* halo, const T* btile) __attribute__((always_inline)) {
-#pragma unroll 1
-        for (int kc = 0; kc < NKCH; ++kc) {
-            if constexpr (sizeof(T) == 2) {
-                // lane group g covers pixels 8g..8g+7 of the 32-pixel chunk: row = 2*kc + (g>>1), x = 8*(g&1) + 0..7;
-                // this lane supplies pixel +qq, channels 4*pp.. (offsets precomputed once per thread: a_off / b_off)
-                uint4 bf[NTB];
+        if constexpr (sizeof(T) == 2) {
+            // The (32-pixel k-chunk, (tap, 16-row) pair) steps of a tile as ONE software pipeline: the A fragments of the next
+            // WG_DEPTH steps and the B fragments of the next k-chunk are in flight while a step's MFMAs issue.  A pair is one or two
+            // MFMAs (16-32 cycles) against ~130 cycles of transposing-LDS-read latency, and the large-volume kernels run one or two
+            // waves per SIMD: one step ahead left the loop waiting on LDS (3D 16->16 at 112x112x80: 4 us per 256-pixel brick).
+            // lane group g covers pixels 8g..8g+7 of the 32-pixel chunk: row = 2*kc + (g>>1), x = 8*(g&1) + 0..7;
+            // this lane supplies pixel +qq, channels 4*pp.. (offsets precomputed once per thread: a_off / b_off)
+            constexpr int NSTEP = NKCH * MAXP, DEPTH = NSTEP < WG_DEPTH ? NSTEP : WG_DEPTH;
+            auto load_a = [&](int st) __attribute__((always_inline)) -> uint4 {
+                const int kc = st / MAXP, i = st % MAXP;
+                // rows 2kc, 2kc + 1 of the tile: a slab's rows are consecutive halo rows, a brick has TH rows per plane
+                const bf16_t* p = (const bf16_t*)halo + (ZW ? (((2 * kc) / G::TH) * G::STDg * G::HH + ((2 * kc) % G::TH) * ST) * (G::HW * PS) : kc * (2 * ST * G::HW * PS)) + a_off[i];
+                const s16x4 lo = lds_tr16(p), hi = lds_tr16(p + 4 * ST * PS);
+                return __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+            };
+            auto load_b = [&](int kc, uint4 (&bf)[NTB]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int t = 0; t < NTB; ++t) {
                     const bf16_t* bp = (const bf16_t*)btile + b_off + kc * (2 * G::TW * PSB) + t * 16;
                     const s16x4 lo = lds_tr16(bp), hi = lds_tr16(bp + 4 * PSB);
                     bf[t] = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
                 }
-                // software-pipelined over the (tap, 16-row) pairs of this wave: the A fragment of pair i+1 is
-                // requested before the MFMAs of pair i (one wave per SIMD: nothing else hides the LDS latency)
-                const bf16_t* abase = (const bf16_t*)halo + kc * (2 * ST * G::HW * PS);
-                s16x4 lo = lds_tr16(abase + a_off[0]), hi = lds_tr16(abase + a_off[0] + 4 * ST * PS);
+            };
+            uint4 bf[2][NTB], af[DEPTH];
+            load_b(0, bf[0]);
 #pragma unroll
-                for (int i = 0; i < MAXP; ++i) {
-                    if (wave + 4 * i < PAIRS) {                        // wave-uniform
-                        const uint4 af = __builtin_bit_cast(uint4, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
-                        if (i + 1 < MAXP && wave + 4 * (i + 1) < PAIRS) {
-                            lo = lds_tr16(abase + a_off[i + 1 < MAXP ? i + 1 : i]);
-                            hi = lds_tr16(abase + a_off[i + 1 < MAXP ? i + 1 : i] + 4 * ST * PS);
-                        }
+            for (int d = 0; d < DEPTH; ++d) af[d] = load_a(d);
 #pragma unroll
-                        for (int t = 0; t < NTB; ++t) mma8(acc[i][t], af, bf[t]);
-                    }
+            for (int st = 0; st < NSTEP; ++st) {
+                const int kc = st / MAXP, i = st % MAXP;
+                if (i == 0 && kc + 1 < NKCH) load_b(kc + 1, bf[(kc + 1) & 1]);
+                const uint4 a = af[st % DEPTH];
+                if (wave + 4 * i < PAIRS) {                            // wave-uniform (only the last pair of a wave can be missing)
+#pragma unroll
+                    for (int t = 0; t < NTB; ++t) mma8(acc[i][t], a, bf[kc & 1][t]);
                 }
-            } else {
+                if (st + DEPTH < NSTEP) af[st % DEPTH] = load_a(st + DEPTH);
+            }
+        } else {
+#pragma unroll 1
+            for (int kc = 0; kc < NKCH; ++kc) {
                 // fp32: 8 MFMAs of 4 pixels each; lane (channel l15, pixel 4*sub + g)
 #pragma unroll 2
                 for (int sub = 0; sub < 8; ++sub) {

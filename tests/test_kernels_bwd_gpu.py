@@ -307,12 +307,18 @@ def test_lcc_and_box_3d():
     assert (ops.diff_mask(p1.to(DEV), p2.to(DEV), kn.to(DEV), 4, 0.1).cpu() == ots.create_mask_v1(p1, p2, kn, 4, 0.1)).all()
 
 
+@pytest.mark.parametrize("brick", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape,cin,cout,add2", [((2, 10, 14, 14), 32, 32, False), ((1, 9, 13, 20), 16, 16, False), ((2, 5, 7, 7), 64, 128, False),
                                                  ((1, 10, 14, 14), 32, 16, True)])
-def test_wgrad_conv3d_ragged(dtype, shape, cin, cout, add2):
+def test_wgrad_conv3d_ragged(dtype, shape, cin, cout, add2, brick, monkeypatch):
     """3x3x3 weight gradient on ragged grids (the V-Net's 14x14x10 / 7x7x5 levels): lazy BN/ReLU A operand with
-    Dropout3d multipliers, optional skip add, 16- and 32-wide B tiles, bias gradient, accumulation into existing dW."""
+    Dropout3d multipliers, optional skip add, 16- and 32-wide B tiles, bias gradient, accumulation into existing dW.
+    `brick`: the 4 x 4 x 16 brick tiling of the large-volume levels (bf16), forced onto these small ragged grids
+    (D, H not multiples of 4, W not a multiple of 16) through the library's lab knob; off = the 1 x 4 x 16 slabs."""
+    if brick and dtype != torch.bfloat16:
+        pytest.skip("brick tiles are bf16 only")
+    monkeypatch.setenv("CHAP_WGRAD_BRICK", "1" if brick else "0")
     g = torch.Generator().manual_seed(21)
     N, D, H, W = shape
     x = rq(torch.randn(N, cin, D, H, W, generator=g), dtype)

@@ -118,6 +118,25 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (argc > 1 && argv[1][0] == 'd') {       // 2D deep layers with the library's blocking (KC32 NT2 MR2, staged weights)
+        run<3, 32, 2, 2, false>("128->128@32 N12 NT2 MR2", 12, 32, 32, 128, 128, true, true);
+        run<3, 32, 2, 2, false>("256->256@16 N12 NT2 MR2", 12, 16, 16, 256, 256, true, true);
+        run<3, 32, 2, 2, false>("64->64@64 N12 NT2 MR2", 12, 64, 64, 64, 64, true, true);
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'e') {       // 3D deep layers, 1 x 4 x 16 slabs: KC32 (weights streamed from L2 per wave) vs KC16 (staged through LDS)
+        run<3, 32, 2, 1, false, true, false>("3D 64@20x28x28 N2 slab KC32 NT2", 2, 28, 28, 64, 64, true, true, 20);
+        run<3, 16, 2, 1, false, true, false>("3D 64@20x28x28 N2 slab KC16 NT2", 2, 28, 28, 64, 64, true, true, 20);
+        run<3, 16, 4, 1, false, true, false>("3D 64@20x28x28 N2 slab KC16 NT4", 2, 28, 28, 64, 64, true, true, 20);
+        run<3, 16, 2, 4, false, true, true>("3D 64@20x28x28 N2 brick KC16 NT2", 2, 28, 28, 64, 64, true, true, 20);
+        run<3, 32, 2, 1, false, true, false>("3D 128@10x14x14 N2 slab KC32 NT2", 2, 14, 14, 128, 128, true, true, 10);
+        run<3, 16, 2, 1, false, true, false>("3D 128@10x14x14 N2 slab KC16 NT2", 2, 14, 14, 128, 128, true, true, 10);
+        run<3, 16, 4, 1, false, true, false>("3D 128@10x14x14 N2 slab KC16 NT4", 2, 14, 14, 128, 128, true, true, 10);
+        run<3, 32, 2, 1, false, true, false>("3D 256@5x7x7 N2 slab KC32 NT2", 2, 7, 7, 256, 256, true, true, 5);
+        run<3, 16, 2, 1, false, true, false>("3D 256@5x7x7 N2 slab KC16 NT2", 2, 7, 7, 256, 256, true, true, 5);
+        run<3, 16, 4, 1, false, true, false>("3D 256@5x7x7 N2 slab KC16 NT4", 2, 7, 7, 256, 256, true, true, 5);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == '3') {
         run<3, 16, 1, 4, true, true, true>("3D 16->16@80x112x112 ZW", 2, 112, 112, 16, 16, true, true, 80);
         run<3, 32, 2, 4, true, true, true>("3D 32->32@40x56x56 ZW", 2, 56, 56, 32, 32, true, true, 40);
