@@ -24,6 +24,7 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
         if (p->dims == 3 && p->ksize == 3 && p->stride == 1 && p->dtype == CHAP_BF16 && min_bricks > 0 && bricks >= min_bricks &&
             p->a[0].C <= 64 && (p->na < 2 || p->a[1].C <= 64) && p->b.C <= 64) { q->brick = 1; q->KC = 16; }      // (<= 64 channels per source: the brick kernels' small scale/shift cache)
     }
+    // (tried: 16 x 16 tiles for the 2D 16-channel levels -- 16->16 at 256x256 35.8 -> 32.9 us with 512 blocks, 16+16->16 unchanged: not kept)
     CHAP_CHECK_ARG(q->Ca % q->KC == 0, "chap_wgrad: Ca=%d not a multiple of %d", q->Ca, q->KC);
     q->taps = p->ksize * p->ksize * (p->dims == 3 ? p->ksize : 1);
     const bool small_tile = (p->dims == 3 && p->ksize >= 2);   // 3D geometries use 4 x 16 tiles (MR = 1)
