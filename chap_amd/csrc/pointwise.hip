@@ -232,6 +232,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const chap_bn_finalize
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= P.C) return;
     const int nslots = *(const int*)P.stats;
+    // the per-channel parameters are requested NOW, next to the header and the slots: behind the reduction they were a third
+    // dependent memory round trip of a kernel that is nothing but latency
+    const bool upd = P.momentum > 0.f && P.running_mean;
+    const float gam = P.gamma[c], bet = P.beta[c], sft = P.stats_shift ? P.stats_shift[c] : 0.f;
+    const float rm0 = upd ? P.running_mean[c] : 0.f, rv0 = upd ? P.running_var[c] : 0.f;
     const int nsub = P.Clog / P.C;
     const float* st = P.stats + CHAP_STATS_HDR;
     double s = 0.0, q = 0.0;
@@ -260,16 +265,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const chap_bn_finalize
     const double ms = s / cnt;                                   // mean of (x - shift)
     double var = q / cnt - ms * ms;
     var = var > 0.0 ? var : 0.0;
-    const float mean = (float)((P.stats_shift ? (double)P.stats_shift[c] : 0.0) + ms);
+    const float mean = (float)((double)sft + ms);
     const float invstd = (float)(1.0 / sqrt(var + (double)P.eps));
-    const float sc = P.gamma[c] * invstd;
+    const float sc = gam * invstd;
     P.scale[c] = sc;
-    P.shift[c] = P.beta[c] - mean * sc;
+    P.shift[c] = bet - mean * sc;
     if (P.mean) { P.mean[c] = mean; P.invstd[c] = invstd; }
-    if (P.momentum > 0.f && P.running_mean) {
+    if (upd) {
         const float unb = (float)(cnt > 1.0 ? var * cnt / (cnt - 1.0) : var);
-        P.running_mean[c] = (1.f - P.momentum) * P.running_mean[c] + P.momentum * mean;
-        P.running_var[c] = (1.f - P.momentum) * P.running_var[c] + P.momentum * unb;
+        P.running_mean[c] = (1.f - P.momentum) * rm0 + P.momentum * mean;
+        P.running_var[c] = (1.f - P.momentum) * rv0 + P.momentum * unb;
     }
 }
 extern "C" int chap_bn_finalize(const chap_bn_finalize_params* p, void* stream) {
