@@ -2,6 +2,7 @@
 #include <cstdlib>
 #include "common.h"
 
+int chap_conv_launch_kpar_bf16(const chap_conv_params* p, int KC, int cpar, hipStream_t s);
 #define DECL_GEOM(dt, g) int chap_conv_launch_##dt##_g##g(const chap_conv_params* p, int KC, int NT, int MR, hipStream_t s);
 DECL_GEOM(bf16, 1) DECL_GEOM(bf16, 2) DECL_GEOM(bf16, 3) DECL_GEOM(bf16, 4) DECL_GEOM(bf16, 5)
 DECL_GEOM(f32, 1) DECL_GEOM(f32, 2) DECL_GEOM(f32, 3) DECL_GEOM(f32, 4) DECL_GEOM(f32, 5)
@@ -103,6 +104,22 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
             if (ent && atoi(ent) > 0 && atoi(ent) <= b.ntiles) NT = atoi(ent);
             if (emr && atoi(emr) > 0) MR = atoi(emr);
         }
+    }
+    // ---- the deep, small 3x3(x3) layers: K-chunks side by side (conv_kpar.h) instead of one after the other
+    if (p->dtype == CHAP_BF16 && (geom == 1 || geom == 2) && p->out_mode == 0 && !p->out_planar && (p->Cout & 3) == 0 &&
+        (p->nsrc == 1 || (p->combine == 0 && p->src[0].C % b.KC == 0)) && !(d3 && (p->src[0].keep || (p->nsrc > 1 && p->src[1].keep)))) {
+        // Measured per layer shape (tools/shape_table.py with CHAP_CONV_KPAR = 0 / 1, gpurun_out/kpar*.log), kernel alone: it wins while the
+        // launch is about one wave of blocks -- 3D 256->256 at 7x7x5 23.3 -> 14.4 us, 128->128 at 14x14x10 20.5 -> 17.0, 256->128 39.1 -> 29.6;
+        // 2D 128->256 at 32x32 20.4 -> 14.7, 256->256 at 16x16 15.2 -> 10.8, 128+128->128 23.5 -> 19.2 -- and loses where a CU gets several
+        // tiles, which conv_fwd_kernel's persistent blocks overlap (3D 64->64 at 28x28x20, 1120 blocks: 24.4 -> 30.8).  Inside the
+        // iteration the 3D step gains 0.8 % (18.32 -> 18.17 ms, three A/B pairs); the 2D step does NOT (7.62 -> 7.69 ms: there the
+        // weights are not L2-hot as in the stand-alone timing, and a wave's fragment ring covers an L2 hit, not a MALL round trip), so
+        // by default only the 3D layers take this kernel.
+        const char* ek = getenv("CHAP_CONV_KPAR");            // lab knob: 0 = never, 1 = whenever eligible; default: 3D, by the block count
+        const int mode = ek ? atoi(ek) : 2;
+        const int cpar = b.nchunks % 4 == 0 ? 4 : (b.nchunks % 2 == 0 ? 2 : 0);
+        const long kblocks = (long)p->N * p->D * cdiv(p->H, d3 ? 4 : 8) * cdiv(p->W, 16) * cdiv(b.ntiles, 2);
+        if (cpar && Ck >= 64 && (mode == 1 || (mode == 2 && d3 && kblocks <= 800))) return chap_conv_launch_kpar_bf16(p, b.KC, cpar, (hipStream_t)stream);
     }
     static const conv_launch_fn table[2][5] = {
         {chap_conv_launch_f32_g1, chap_conv_launch_f32_g2, chap_conv_launch_f32_g3, chap_conv_launch_f32_g4, chap_conv_launch_f32_g5},

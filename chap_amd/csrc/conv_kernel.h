@@ -289,7 +289,6 @@ __device__ __forceinline__ void keep8(float v[8], uint2 keep, float keep_scale) 
 template <typename T, int KC, bool ADD2, int UNITS, bool LANESEL, bool KEEPM, bool ONE, int AFFC = CONV_MAX_AFFINE_C>
 __device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2, KEEPM>& R, const unit_desc<UNITS>& U, T* halo, const src_scalars& s0, const src_scalars& s1,
                                                  const float* aff, bool plain, int n, int chunk) {
-    typedef typename frag<T>::type F;
     // no per-unit branches: a path that skips a unit would leave its prefetch load un-waited as far as the compiler
     // can tell, and the next item's issue phase would then wait for every outstanding memory operation
     if (plain) {

@@ -376,3 +376,64 @@ def test_conv3x3_2d_bench_shapes_ragged(dtype, N, hw, cin, cout):
     assert torch.equal(first[:L.STATS_HDR + nslots * 2 * cout].view(torch.int32), stats[:L.STATS_HDR + nslots * 2 * cout].view(torch.int32))
     assert relerr(st[0], ref.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
     assert relerr(st[1], (ref * ref).sum((0, 2, 3))) < 1e-3 + TOL[dtype]
+
+
+@pytest.mark.parametrize("dims,shape,c0,c1,cout", [
+    (2, (3, 1, 30, 34), 128, 0, 128),      # 4 chunks side by side, ragged 2D grid
+    (2, (2, 1, 16, 16), 256, 0, 256),      # two rounds of 4 chunks
+    (2, (2, 1, 17, 40), 64, 64, 64),       # two concatenated sources (decoder), 4 chunks
+    (2, (2, 1, 20, 24), 64, 0, 100),       # 2 chunks side by side, Cout not a multiple of 32
+    (3, (2, 10, 14, 14), 128, 0, 128),     # 3D slabs, 4 chunks
+    (3, (1, 5, 7, 7), 256, 0, 128),        # 3D, two rounds
+    (3, (2, 9, 13, 20), 64, 0, 64),        # 3D, 2 chunks side by side
+])
+def test_conv3x3_k_parallel(dims, shape, c0, c1, cout, monkeypatch):
+    """The deep, small layers' kernel (csrc/conv_kpar.h: the K-chunks of a tile side by side, partial sums joined in LDS in a
+    fixed order), forced through the library's knob: lazy BN-affine + LeakyReLU sources, Dropout keep mask (2D) / Dropout3d
+    channel multipliers (3D), bias, shifted statistics -- against torch, and against conv_fwd_kernel on the same inputs."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(7)
+    N, D, H, W = shape
+    sp = (H, W) if dims == 2 else (D, H, W)
+    cin = c0 + c1
+    xs, lazies, refs = [], [], []
+    for ci, c in enumerate([c0, c1]):
+        if c == 0:
+            continue
+        x = rq(torch.randn(N, c, *sp, generator=g), dtype)
+        sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+        keep = cm = None
+        if ci == 0 and dims == 2:
+            keep = (torch.rand(N, c, *sp, generator=g) > 0.3).float()
+        if ci == 0 and dims == 3:
+            cm = (torch.rand(N, c, generator=g) > 0.3).float() * 1.5
+        ref = lazy_ref(x, sc, sh, 0.01, keep, 1.0 / 0.7)
+        if cm is not None:
+            ref = ref * cm.view(N, c, 1, 1, 1)
+        refs.append(rq(ref, dtype))
+        kd = None if keep is None else cl(keep, torch.uint8)
+        lazies.append(ops.Lazy(cl(x, dtype), sc.to(DEV), sh.to(DEV), True, 0.01, keep=kd, keep_scale=1.0 / 0.7,
+                               chan_mul=None if cm is None else cm.to(DEV)))
+    a = torch.cat(refs, 1)
+    w = torch.randn(cout, cin, *([3] * dims), generator=g) / (cin * 3 ** dims) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = (F.conv2d if dims == 2 else F.conv3d)(a, rq(w, dtype), b, padding=1)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, cin, cout, 3 ** dims)
+    cshift = torch.randn(cout, generator=g)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CHAP_CONV_KPAR", mode)
+        out = torch.full((N, D, H, W, cout), float("nan"), device=DEV, dtype=dtype)
+        stats = ops.stats_buffer(cout, DEV)
+        ops.conv_fwd(lazies, wp, b.to(DEV), cout, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=dims,
+                     stats=stats, stats_shift=cshift.to(DEV))
+        torch.cuda.synchronize()
+        got[mode] = (uncl(out), ops.stats_totals(stats, cout).float().cpu())
+    o1, s1 = got["1"]
+    refc = ref if dims == 3 else ref.unsqueeze(2)
+    assert torch.isfinite(o1).all()
+    assert relerr(o1, refc) < TOL[dtype]
+    assert relerr(o1, got["0"][0]) < 1e-2                        # both round the same fp32 sums to bf16: a last-bit difference at most
+    rc = refc - cshift.view(1, -1, 1, 1, 1)
+    assert relerr(s1[0], rc.sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
+    assert relerr(s1[1], (rc * rc).sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]

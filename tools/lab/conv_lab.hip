@@ -88,6 +88,16 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (argc > 1 && argv[1][0] == 'l') {       // 3D level 1 (32 channels at 40x56x56): bricks with KC16, NT / weight residency variants
+        run<3, 16, 2, 4, true, true, true>("3D 32->32@40x56x56 ZW KC16 NT2 WLDS", 2, 56, 56, 32, 32, true, true, 40);
+        run<3, 16, 2, 4, false, true, true>("3D 32->32@40x56x56 ZW KC16 NT2 stg", 2, 56, 56, 32, 32, true, true, 40);
+        run<3, 16, 1, 4, true, true, true>("3D 32->32@40x56x56 ZW KC16 NT1 WLDS", 2, 56, 56, 32, 32, true, true, 40);
+        run<3, 16, 1, 4, false, true, true>("3D 32->32@40x56x56 ZW KC16 NT1 stg", 2, 56, 56, 32, 32, true, true, 40);
+        run<3, 16, 2, 4, true, true, true>("3D 64->32@40x56x56 ZW KC16 NT2 WLDS", 2, 56, 56, 64, 32, true, true, 40);
+        run<3, 16, 2, 4, false, true, true>("3D 64->32@40x56x56 ZW KC16 NT2 stg", 2, 56, 56, 64, 32, true, true, 40);
+        run<3, 16, 1, 4, true, true, true>("3D 64->32@40x56x56 ZW KC16 NT1 WLDS", 2, 56, 56, 64, 32, true, true, 40);
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'k') {       // 3D: KC16 bricks vs KC32
         run<3, 16, 2, 4, true, true, true>("3D 32->32@40x56x56 ZW KC16 NT2 WLDS", 2, 56, 56, 32, 32, true, true, 40);
         run<3, 16, 2, 4, false, true, true>("3D 32->32@40x56x56 ZW KC16 NT2 stg", 2, 56, 56, 32, 32, true, true, 40);
