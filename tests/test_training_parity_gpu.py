@@ -53,12 +53,14 @@ def soft_pred_oracle(sd, vol):
         return torch.softmax((o1 + o2) / 2.0, dim=1)
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-2), (torch.bfloat16, 2.5e-1)])
-def test_k_iterations_match_oracle(dtype, tol):
+@pytest.mark.parametrize("dtype,tol_mean,tol_max", [(torch.float32, 1e-2, 1.5e-1), (torch.bfloat16, 6e-2, 8e-1)])
+def test_k_iterations_match_oracle(dtype, tol_mean, tol_max):
     """K full iterations with identical injected randomness: the ensemble probabilities of the two trained
     models (eval mode) agree; the loss trajectories agree.  Tolerances: the iteration is discontinuous in the
     weights (arg-max pseudo labels, largest-CC filter) and the 64x64 fixture has tiny-batch BatchNorm, so two
-    fp32 implementations with different summation orders drift by ~1e-3 per iteration."""
+    fp32 implementations with different summation orders drift by ~1e-3 per iteration.  Bounds = 2.5x the measured deviations
+    (round 2, deterministic reductions: fp32 mean 4.2e-3 / max 5.9e-2 of a probability, bf16 2.7e-2 / 0.41 -- single pixels flip class;
+    what bf16 training is worth is gated by the Dice test in test_parity_gates_gpu.py)."""
     K, B, lbs, H, W = 5, 8, 4, 64, 64
     U = B - lbs
     args = dict(labeled_bs=lbs, batch_size=B, vat_iters=1, base_lr=0.01)
@@ -92,7 +94,7 @@ def test_k_iterations_match_oracle(dtype, tol):
         o = m(val.to(DEV))
         p_hip = torch.softmax((o[0] + o[1]) / 2.0, dim=1).cpu()
     diff = (p_ref - p_hip).abs()
-    assert diff.mean().item() < tol / 2 and diff.max().item() < 8 * tol, (diff.mean().item(), diff.max().item())
+    assert diff.mean().item() < tol_mean and diff.max().item() < tol_max, (diff.mean().item(), diff.max().item())
 
 
 def test_trained_model_dice_matches_oracle_inference():
@@ -158,8 +160,8 @@ def test_resume_continues_the_run():
     m_a, s_a = fresh()
     run(s_a, range(4))
     np.random.seed(99)
-    m_a2, s_a2 = fresh()                                               # the same run again: the noise floor of the comparison
-    run(s_a2, range(4))                                                # (float atomics in the BN sums x arg-max pseudo labels)
+    m_a2, s_a2 = fresh()                                               # the same run again: bit-identical (no float atomics, round 2)
+    run(s_a2, range(4))
     np.random.seed(99)
     m_b, s_b = fresh()
     run(s_b, range(2))
@@ -172,6 +174,6 @@ def test_resume_continues_the_run():
     assert torch.equal(s_c.opt.mom, s_b.opt.mom) and all(torch.equal(v, m_c.state_dict()[k]) for k, v in m_b.state_dict().items())
     run(s_c, range(2, 4))
     noise, resumed = dist(m_a, m_a2), dist(m_a, m_c)
-    assert resumed <= 8 * max(noise, 2e-4), (resumed, noise)           # `noise` is itself one draw of a chaotic quantity
+    assert noise == 0.0 and resumed == 0.0, (noise, resumed)           # a resumed run continues BIT FOR BIT (parameters, momentum, BN buffers, RNG epochs, box RNG)
     wrong = dist(m_a, m_b)                                             # a run that stopped after 2 iterations is far away
     assert wrong > 3 * resumed, (wrong, resumed)
