@@ -1,5 +1,5 @@
 """Where does the iteration's wall time go?  Graph-replay time of ChapStep with parts switched off
-(CHAP_ABL: full | novat | noconc)."""
+(modes: full | novat | noconc | nob = without pass B: the VAT chain alone | nofork = decoders back to back)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,6 +22,11 @@ def run(cfg, mode):
     if mode == "novat": a["adv_noise"] = False
     if mode == "noconc": a["concurrent"] = False
     step = ChapStep(m, a)
+    if mode == "nob":
+        step._phase_b = lambda ctx: []
+    if mode == "nofork":
+        import contextlib
+        step._decoder_fork = lambda origin: contextlib.nullcontext()
     vol, lab = vol.to(dev), lab.to(dev)
     step.capture(vol, lab)
     for _ in range(3): step.replay(vol, lab)
@@ -32,5 +37,5 @@ def run(cfg, mode):
 
 if __name__ == "__main__":
     for cfg in ("2d", "3d"):
-        for mode in ("full", "novat", "noconc"):
+        for mode in ("full", "novat", "noconc", "nob", "nofork"):
             run(cfg, mode)
