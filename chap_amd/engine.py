@@ -198,6 +198,14 @@ class Executor:
         branches = sorted({op.branch for op in prog.ops})
         side = self._side_stream(cur_stream) if len(branches) > 2 else None
 
+        # Dropout seeds are drawn HERE, in program order: the order in which the ops are ISSUED depends on whether this pass
+        # may fork its second decoder (eager / captured, which stream), and a seed must not (round 2: the early VAT pass drew
+        # other masks whenever its stream happened to be the capture's origin stream)
+        drop_seed = {}
+        if train and drop_masks is None:
+            for op_ in prog.ops:
+                if op_.drop:
+                    drop_seed[id(op_)] = rng.next_seed()
         def run_op(op, V=vals, n=N):      # V / n: value table and batch size (the decoders of a perturbed pass see their own)
             nonlocal apos
             k = op.kind
@@ -300,7 +308,7 @@ class Executor:
                         keep = drop_masks.get(site)
                     else:
                         keep = torch.empty(out.shape, dtype=torch.uint8, device=dev)
-                        ops.keep_mask(keep, rng.next_seed(), p, seed_dev=rng.seed_dev)
+                        ops.keep_mask(keep, drop_seed[id(op)], p, seed_dev=rng.seed_dev)
                     if keep is not None:
                         lz.keep, lz.keep_scale = keep, 1.0 / (1.0 - p)
                 else:
@@ -308,7 +316,7 @@ class Executor:
                         cm = drop_masks.get(site)
                     else:
                         cm = torch.empty(n, op.cout, dtype=torch.float32, device=dev)
-                        ops.chan_mask(cm, rng.next_seed(), p, seed_dev=rng.seed_dev)
+                        ops.chan_mask(cm, drop_seed[id(op)], p, seed_dev=rng.seed_dev)
                     if cm is not None:
                         lz.chan_mul = cm
             V[op.out] = lz

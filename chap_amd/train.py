@@ -9,6 +9,7 @@ definitions (oracle/train_step.py).
 """
 import contextlib
 import math
+import os
 
 import numpy as np
 import torch
@@ -55,6 +56,20 @@ class FusedSGD:
         flat, grad = self.model.flat_buffers()
         ops.sgd_step(flat, grad, self.mom, self.lr_dev, self.momentum, self.weight_decay, grad_scale, True, grad2)
         self.model.mark_params_dirty()
+
+
+def _distinct_streams(dev, n):
+    """n streams with pairwise different handles, none of them the current or the default stream."""
+    seen = {0, torch.cuda.current_stream(dev).cuda_stream}
+    out = []
+    for _ in range(256):
+        s = torch.cuda.Stream(device=dev)
+        if s.cuda_stream not in seen:
+            seen.add(s.cuda_stream)
+            out.append(s)
+            if len(out) == n:
+                return out
+    raise RuntimeError("chap_amd: could not get %d distinct streams from the pool" % n)
 
 
 class VAT2d:
@@ -215,14 +230,20 @@ class ChapStep:
         model.swap_grad_buffer(self.grad_both[:n])
         self.grad2 = self.grad_both[n:]
         self.concurrent = bool(a.get("concurrent", True))
-        self._side = torch.cuda.Stream(device=dev) if self.concurrent else None
+        # Streams come from PyTorch's per-device pool (32 of them, handed out round-robin): two "new" streams of a long-lived
+        # process can be the SAME stream.  The ones of an iteration must differ from each other and from the stream the graph is
+        # captured on (pass B on the capture's origin stream would run behind the VAT chain, not beside it), so they are drawn
+        # until they do and the capture gets a stream of its own.
+        st = _distinct_streams(dev, 4)
+        self._cap = st[3]                                          # origin stream of capture()
+        self._side = st[0] if self.concurrent else None
         # Decoder-level concurrency inside a captured graph.  On ROCm 7.2 a captured stream may fork/join with the
         # capture's ORIGIN stream any number of times, but an event dependency between two forked streams crashes
         # hipStreamEndCapture.  So the long chain of the iteration (the VAT branch: K+1 forward/backward pairs)
         # stays on the origin stream, where the executor may fork its second decoder, and the short one (pass B)
         # goes to the side stream with its decoders back to back.
-        self._d2 = torch.cuda.Stream(device=dev) if self.concurrent else None
-        self._pre = torch.cuda.Stream(device=dev) if self.concurrent else None      # the VAT pre-pass beside pass A
+        self._d2 = st[1] if self.concurrent else None
+        self._pre = st[2] if self.concurrent else None              # the VAT pre-pass beside pass A
 
     # ------------------------------------------------------------------ host-side schedule values
     def prepare(self, box_yx=None):
@@ -343,9 +364,10 @@ class ChapStep:
                    lab_a=label_batch[:lsub], lab_b=label_batch[lsub:lbs], uimg_ab=volume_batch[lbs:])
         # ---- the first VAT power-iteration forward (x + xi * d) needs nothing from pass A: it runs beside it on its own stream
         main = torch.cuda.current_stream()
-        # (`vat_early`, default off: 2D 7.78 -> 7.58 ms, 3D 19.48 -> 19.12 ms per step, but with it two identical runs are no longer
-        #  bitwise equal in every process state -- tools/lab/nondet_probe5.py -- and reproducibility is what the parity gates test)
-        pre = self._pre if (self.concurrent and a["adv_noise"] and a.get("vat_early", False)) else None
+        # (`vat_early`, default on since the end of round 2: 2D 7.60 -> 7.41 ms, 3D 18.29 -> 17.75 ms per step.  It had been off because
+        #  two identical runs were not always bitwise equal with it; the cause was not this overlap but dropout seeds drawn in ISSUE
+        #  order -- see Executor.forward -- together with stream handles repeating in PyTorch's pool, see ChapStep.__init__.)
+        pre = self._pre if (self.concurrent and a["adv_noise"] and a.get("vat_early", True)) else None
         model.prepare_weights()                  # before the streams fork: every pass of the iteration reads the same packed copies
         if a["adv_noise"]:
             if pre is not None:
@@ -508,13 +530,13 @@ class ChapStep:
         g = torch.cuda.CUDAGraph()
         dp = self.grad_sync is not None
         # thread_local: the RCCL watchdog thread polls events while we capture (global mode would abort on that)
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        with torch.cuda.graph(g, stream=self._cap, capture_error_mode="thread_local"):
             self.model._rng.seed_dev.add_(1)
             self._static_out = self.device_step(self._static_v, self._static_l, inject, update=not dp)
         self._graph, self._graph_opt, self._graphs_dp = g, None, None
         if dp:          # data-parallel without the two-branch schedule: [compute graph] -> RCCL all-reduce (eager) -> [optimizer graph]
             g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, pool=g.pool(), capture_error_mode="thread_local"):
+            with torch.cuda.graph(g2, pool=g.pool(), stream=self._cap, capture_error_mode="thread_local"):
                 self.opt.step(grad_scale=1.0 / self.world_size, grad2=self.grad2)
             self._graph_opt = g2
         return g
@@ -529,7 +551,7 @@ class ChapStep:
         B and V are captured into SEPARATE memory pools (they run concurrently at replay: sharing a pool would let one
         reuse memory the other has freed during capture); what crosses graph boundaries (pass A's outputs) is kept alive
         by `self._dp_ctx`.  Each capture's origin stream forks its own second-decoder stream."""
-        kw = dict(capture_error_mode="thread_local")
+        kw = dict(capture_error_mode="thread_local", stream=self._cap)
         stack = contextlib.ExitStack()
         gA, gB, gV, gO = (torch.cuda.CUDAGraph() for _ in range(4))
         with torch.cuda.graph(gA, **kw):

@@ -292,3 +292,44 @@ def test_iteration_with_channel_dropout_matches_oracle():
     torch.cuda.synchronize()
     after2 = m2.state_dict()
     assert all(torch.equal(after[k], after2[k]) for k in after), [k for k in after if not torch.equal(after[k], after2[k])][:5]
+
+
+def test_dropout_masks_do_not_depend_on_the_issue_order():
+    """Regression (round 2): the executor issues the second decoder's ops first when it may fork a stream for it and in program
+    order when it may not (captured pass on a non-origin stream), and the dropout seeds used to be drawn in ISSUE order -- the
+    same pass drew other masks depending on the stream it ran on.  Seeds are drawn in program order now: a train-mode forward
+    with the device RNG gives bit-identical logits with and without the fork, for the 2D and the 3D network."""
+    from chap_amd.networks import DualDecoder3d
+    for make, shape in ((lambda: DualDecoder(1, 4, {"decoder_type": "mcnet"}), (4, 1, 64, 64)),
+                        (lambda: DualDecoder3d(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True), (2, 1, 32, 32, 16))):
+        torch.manual_seed(5)
+        m = make().to(DEV).train()
+        x = torch.randn(*shape, device=DEV)
+        with torch.no_grad():
+            m(x, update_stats=False)                            # builds the executor and its RNG
+        outs = []
+        for fork in (True, False):
+            m._rng.reset_counter()
+            if not fork:
+                orig = m._exec._side_stream
+                m._exec._side_stream = lambda parent: None
+            with torch.no_grad():
+                o = m(x, update_stats=False)
+            if not fork:
+                m._exec._side_stream = orig
+            torch.cuda.synchronize()
+            outs.append([t.clone() for t in o])
+        assert all(torch.equal(a, b) for a, b in zip(*outs))
+        assert not torch.equal(outs[0][0], outs[0][1])          # the two decoders do differ (dropout, mcnet up-sampling)
+
+
+def test_chapstep_streams_are_distinct():
+    """PyTorch hands out the streams of its per-device pool round-robin, so two 'new' streams of a long-lived process can be
+    the same stream; the iteration's streams and the capture's origin stream are drawn until they differ."""
+    keep = [torch.cuda.Stream() for _ in range(70)]             # walk the pool past its size
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train()
+    for _ in range(3):
+        s = ChapStep(m, dict(labeled_bs=4, batch_size=8))
+        handles = [t.cuda_stream for t in (s._side, s._d2, s._pre, s._cap)]
+        assert len(set(handles)) == 4 and 0 not in handles and torch.cuda.current_stream().cuda_stream not in handles
+    del keep
