@@ -525,7 +525,10 @@ class ChapStep:
             torch.cuda.synchronize()
         self.model._rng.reset_counter()
         self.prepare()
-        if self.grad_sync is not None and type(self)._iteration is ChapStep._iteration and self.concurrent and self.args["adv_noise"]:
+        # the four-graph form only when bucket 0 is to be all-reduced beside the VAT chain; the fold schedule exchanges once, at the
+        # end: [compute graph] -> all-reduce -> [optimizer graph] keeps pass B and the VAT chain as forked branches of ONE graph
+        if (self.grad_sync is not None and getattr(self.grad_sync, "overlap", False) and type(self)._iteration is ChapStep._iteration
+                and self.concurrent and self.args["adv_noise"]):
             return self._capture_dp(inject)
         g = torch.cuda.CUDAGraph()
         dp = self.grad_sync is not None
