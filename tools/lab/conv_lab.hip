@@ -157,6 +157,7 @@ int main(int argc, char** argv) {
     }
     run<3, 16, 1, 4, true>("16->16@256 MR4 pro+stats", 12, 256, 256, 16, 16, true, true);
     run<3, 16, 1, 2, true>("16->16@256 MR2 pro+stats", 12, 256, 256, 16, 16, true, true);
+    run<3, 16, 1, 8, true>("16->16@256 MR8 pro+stats", 12, 256, 256, 16, 16, true, true);
     run<3, 32, 2, 4, true>("32->32@128 MR4 pro+stats", 12, 128, 128, 32, 32, true, true);
     run<3, 32, 4, 2, true>("64->64@64 MR2 pro+stats", 12, 64, 64, 64, 64, true, true);
     run<3, 32, 4, 2, false>("128->128@32 MR2", 12, 32, 32, 128, 128, true, true);
