@@ -717,11 +717,17 @@ __global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES :
                             const int row = ZW ? m : wave * MR + m;
                             const bool valid = decltype(FULL)::value || (xok && zok && cok && (y0 + row < P.H));
                             float v[4];
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = acc[m][t][j] + bj[t][j];
+                            // packed fp32 (v_pk_add_f32 / v_pk_fma_f32): bias, shifted moments -- the epilogue is VALU time of a VALU-bound kernel
+                            const f32x2 v0 = (f32x2){acc[m][t][0], acc[m][t][1]} + (f32x2){bj[t][0], bj[t][1]};
+                            const f32x2 v1 = (f32x2){acc[m][t][2], acc[m][t][3]} + (f32x2){bj[t][2], bj[t][3]};
+                            v[0] = v0.x; v[1] = v0.y; v[2] = v1.x; v[3] = v1.y;
                             if (do_stats) {
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) { const float vs = valid ? v[j] - cj[t][j] : 0.f; ssum[t][j] += vs; ssq[t][j] += vs * vs; }
+                                f32x2 d0 = v0 - (f32x2){cj[t][0], cj[t][1]}, d1 = v1 - (f32x2){cj[t][2], cj[t][3]};
+                                if (!decltype(FULL)::value) { d0.x = valid ? d0.x : 0.f; d0.y = valid ? d0.y : 0.f; d1.x = valid ? d1.x : 0.f; d1.y = valid ? d1.y : 0.f; }
+                                const f32x2 s0 = (f32x2){ssum[t][0], ssum[t][1]} + d0, s1 = (f32x2){ssum[t][2], ssum[t][3]} + d1;
+                                const f32x2 q0 = d0 * d0 + (f32x2){ssq[t][0], ssq[t][1]}, q1 = d1 * d1 + (f32x2){ssq[t][2], ssq[t][3]};
+                                ssum[t][0] = s0.x; ssum[t][1] = s0.y; ssum[t][2] = s1.x; ssum[t][3] = s1.y;
+                                ssq[t][0] = q0.x; ssq[t][1] = q0.y; ssq[t][2] = q1.x; ssq[t][3] = q1.y;
                             }
                             if (CHAP_ABLATE & 8) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
                             const unsigned oi = (unsigned)(row * orow + zw_off + ooff[t]);
