@@ -1,5 +1,6 @@
 // chap_conv_fwd / chap_pack_weights: argument checks, blocking choice, weight packing kernel.
 #include <cstdlib>
+#include <atomic>
 #include "common.h"
 
 int chap_conv_launch_kpar_bf16(const chap_conv_params* p, int KC, int cpar, hipStream_t s);
@@ -149,14 +150,18 @@ __device__ __forceinline__ void pack_body(const float* __restrict__ w, T* __rest
                                           int KC, int GPT, int NP, int STEPS, int nchunks, int ntiles, int Cn_logical, int Ck_real,
                                           long first, long stride) {
     const long total = (long)nchunks * STEPS * ntiles * 64;
-    for (long i = first; i < total; i += stride) {
-        const int lane = (int)(i & 63);
-        long r = i >> 6;
-        const int nt = (int)(r % ntiles); r /= ntiles;
-        const int step = (int)(r % STEPS);
-        const int chunk = (int)(r / STEPS);
-        const int g = lane >> 4, n16 = lane & 15;
-        const int pp = step * 4 + g;
+    // The units are enumerated with (tap, 8-channel group) fastest, NOT in output order: neighbouring threads then read neighbouring
+    // taps of the same checkpoint rows (a load instruction touches a few cache lines instead of 64 -- the kernel is gather-bound) and
+    // each writes its 16-byte unit to its place in the fragment layout.
+    const int PPS = STEPS * 4;
+    for (long q = first; q < total; q += stride) {
+        const int pp = (int)(q % PPS);
+        long r = q / PPS;
+        const int n16 = (int)(r & 15); r >>= 4;
+        const int nt = (int)(r % ntiles);
+        const int chunk = (int)(r / ntiles);
+        const int step = pp >> 2, g = pp & 3;
+        const long i = ((long)(chunk * STEPS + step) * ntiles + nt) * 64 + g * 16 + n16;
         const int nl = nt * 16 + n16;
         float v[8];
 #pragma unroll
@@ -212,8 +217,12 @@ extern "C" int chap_pack_describe(const chap_pack_params* p, chap_pack_entry* e)
 
 extern "C" int chap_pack_multi(const chap_pack_entry* entries_dev, int32_t n, int64_t max_total, void* stream) {
     CHAP_CHECK_ARG(entries_dev && n > 0 && max_total > 0, "chap_pack_multi: bad argument");
+    // one fragment unit (8 gathered values) per thread and loop step: the largest layer sets the time (3D 256x256x27: 221k units), so it gets
+    // up to 1024 blocks -- 64 made this launch, the first of every iteration, 33 us (2D) / 164 us (3D), now 24 / 103; the small entries'
+    // blocks exit at once.  (Tried: one block per (K-chunk, 16-channel tile) reading its runs of the checkpoint tensor coalesced into
+    // LDS: fewer, longer blocks -- 58 / 153 us.)
     long bx = (max_total + 255) / 256;
-    if (bx > 64) bx = 64;
+    if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(pack_multi_kernel, dim3((unsigned)bx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, entries_dev);
     CHAP_LAUNCH_CHECK("chap_pack_multi");
     return CHAP_OK;
