@@ -204,6 +204,8 @@ class ChapStep:
         # [BCP box: 4 / 6 int32 | consistency weight f32 | learning rate f32]
         nbox = 4 if self.dims == 2 else 6
         self._sched = torch.zeros(8, dtype=torch.int32, device=dev)
+        self._sched_pin = [torch.empty(8, dtype=torch.int32).pin_memory() for _ in range(4)]      # host side of the schedule block (see _upload_sched)
+        self._sched_ev, self._sched_k = [None] * 4, 0
         self.box = self._sched[:nbox]
         self.cw_dev = self._sched[6:7].view(torch.float32)
         if isinstance(self.opt, FusedSGD):                       # the optimizer reads its lr from the same block
@@ -259,7 +261,19 @@ class ChapStep:
         import struct
         f2i = lambda v: struct.unpack("<i", struct.pack("<f", float(v)))[0]
         vals = list(box_vals) + [0] * (6 - len(box_vals)) + [f2i(cw), f2i(self.opt.param_groups[0]["lr"])]
-        self._sched.copy_(torch.tensor(vals, dtype=torch.int32))
+        # Through a small ring of PINNED host blocks, asynchronously: a plain `copy_` from pageable memory synchronises the stream,
+        # i.e. the host would wait for the previous iteration to drain before it even starts launching the next one (the GPU then
+        # idles while the graph's first nodes are being submitted: ~0.5 ms of gaps at the head of every replay in the kernel trace).
+        # A slot is reused only after the copy that last read it has run (event), which also bounds how far the host runs ahead.
+        k = self._sched_k
+        self._sched_k = (k + 1) % len(self._sched_pin)
+        if self._sched_ev[k] is not None:
+            self._sched_ev[k].synchronize()
+        self._sched_pin[k].copy_(torch.tensor(vals, dtype=torch.int32))
+        self._sched.copy_(self._sched_pin[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._sched_ev[k] = ev
 
     def finish(self):
         """poly LR applied AFTER the step (train_ours_2D.py:385-389)."""
