@@ -14,15 +14,17 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     CHAP_CHECK_ARG(q->Ca % 16 == 0 && q->Cb % 8 == 0, "chap_wgrad: Ca=%d must be a multiple of 16, Cb=%d of 8", q->Ca, q->Cb);
     q->KC = (q->Ca >= 32 && q->Ca % 32 == 0) ? 32 : 16;
     if (p->dtype == CHAP_F32 && p->ksize == 2) q->KC = 16;      // fp32 k2 s2 halos: two buffers of 32 channels exceed the 160 KiB LDS
-    // 3D 3x3x3, bf16: 4 x 4 x 16 bricks with 16-channel A chunks once the volume has enough of them (the 1 x 4 x 16 slab stages
-    // 5.1 A-pixels per output pixel and pays a barrier + a prefetch round trip per 64 pixels; the brick 2.5 and one per 256)
+    // 3D 3x3x3, bf16: 4 x 4 x 16 bricks with 16-channel A chunks (the 1 x 4 x 16 slab stages 5.1 A-pixels per output pixel and pays a
+    // barrier + a prefetch round trip per 64 pixels; the brick 2.5 and one per 256).  Threshold swept on the whole 3D iteration
+    // (CHAP_WGRAD_BRICK = 2048 / 512 / 128 / 16 / 4 bricks: 17.87 / 17.65 / 17.33 / 17.17 / 17.17 ms per step): everything but the 7x7x5 level
+    // (8 bricks, all the same) gains.
     q->brick = 0;
     {
         const char* eb = getenv("CHAP_WGRAD_BRICK");        // lab knob: 0 = slabs everywhere, N = bricks from N bricks up
-        const long min_bricks = eb ? atol(eb) : 512;
+        const long min_bricks = eb ? atol(eb) : 16;
         const long bricks = (long)p->N * cdiv(p->D, 4) * cdiv(p->H, 4) * cdiv(p->W, 16);
         if (p->dims == 3 && p->ksize == 3 && p->stride == 1 && p->dtype == CHAP_BF16 && min_bricks > 0 && bricks >= min_bricks &&
-            p->a[0].C <= 64 && (p->na < 2 || p->a[1].C <= 64) && p->b.C <= 64) { q->brick = 1; q->KC = 16; }      // (<= 64 channels per source: the brick kernels' small scale/shift cache)
+            p->a[0].C <= 256 && (p->na < 2 || p->a[1].C <= 256) && p->b.C <= 256) { q->brick = 1; q->KC = 16; }      // (<= 256 channels per source: the brick kernels' scale/shift cache)
     }
     // (tried: 16 x 16 tiles for the 2D 16-channel levels -- 16->16 at 256x256 35.8 -> 32.9 us with 512 blocks, 16+16->16 unchanged: not kept)
     CHAP_CHECK_ARG(q->Ca % q->KC == 0, "chap_wgrad: Ca=%d not a multiple of %d", q->Ca, q->KC);

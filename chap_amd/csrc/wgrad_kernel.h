@@ -23,8 +23,8 @@ constexpr int WG_DEPTH = CHAP_WGRAD_DEPTH;      // A fragments (transposing LDS 
 #endif
 // LDS pixel stride of the B tile (elements): 32 (16) channels + padding for the transposing reads
 template <typename T, int BN = WG_BN> __host__ __device__ constexpr int wg_psb() { return sizeof(T) == 2 ? (BN == 16 ? CHAP_WGRAD_PSB16 : 40) : 36; }
-// scale/shift cache per source: the brick kernels run the 16..64-channel levels only and keep it small (LDS for a second block per CU)
-template <bool ZW> __host__ __device__ constexpr int wg_affc() { return ZW ? 128 : CONV_MAX_AFFINE_C; }
+// scale/shift cache per source: the brick kernels run up to 256 channels per source and keep it small (LDS for a second block per CU)
+template <bool ZW> __host__ __device__ constexpr int wg_affc() { return ZW ? 512 : CONV_MAX_AFFINE_C; }
 
 template <typename T, int KS, int ST, bool D3, int KC, int MR, int BN = WG_BN, bool ZW = false>
 __host__ __device__ constexpr size_t wgrad_lds_bytes() {
