@@ -79,6 +79,9 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
         const long bricks = (long)p->N * cdiv(p->D, 4) * cdiv(p->H, 4) * cdiv(p->W, 16);
         if (bricks >= 64) {
             MR = 4;
+            // at most 32 output channels per block: the stand-alone sweeps preferred 64 for the 64-channel level (28x28x20), the whole
+            // 3D iteration does not (17.09 -> 16.79 ms per step with NT = 2: more, smaller blocks share the CUs with the other streams)
+            if (NT > 2) NT = 2;
             while (NT > 1 && bricks * cdiv(b.ntiles, NT) < 128) NT >>= 1;
         } else if (b.KC == 32 && NT > 2) {
             NT = 2;
@@ -120,7 +123,9 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
         const int mode = ek ? atoi(ek) : 2;
         const int cpar = b.nchunks % 4 == 0 ? 4 : (b.nchunks % 2 == 0 ? 2 : 0);
         const long kblocks = (long)p->N * p->D * cdiv(p->H, d3 ? 4 : 8) * cdiv(p->W, 16) * cdiv(b.ntiles, 2);
-        if (cpar && Ck >= 64 && (mode == 1 || (mode == 2 && d3 && kblocks <= 800))) return chap_conv_launch_kpar_bf16(p, b.KC, cpar, (hipStream_t)stream);
+        const char* ekm = getenv("CHAP_CONV_KPAR_MAX");       // lab knob: the block-count threshold
+        const long kmax = ekm ? atol(ekm) : 800;
+        if (cpar && Ck >= 64 && (mode == 1 || (mode == 2 && d3 && kblocks <= kmax))) return chap_conv_launch_kpar_bf16(p, b.KC, cpar, (hipStream_t)stream);
     }
     static const conv_launch_fn table[2][5] = {
         {chap_conv_launch_f32_g1, chap_conv_launch_f32_g2, chap_conv_launch_f32_g3, chap_conv_launch_f32_g4, chap_conv_launch_f32_g5},

@@ -45,7 +45,7 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     const char* env = getenv("CHAP_WGRAD_BLOCKS");          // lab knob for those sweeps
     if (env && atol(env) > 0) target = atol(env);
     else if (p->ksize == 2) target = 256;
-    else if (q->brick) target = q->Cb <= 16 ? 512 : 256;      // 16-wide B tiles leave LDS for two bricks per CU (3D 16->16 at 112x112x80: 88 / 66 / 85 us with 256 / 512 / 768 blocks)
+    else if (q->brick) { const char* eb2 = getenv("CHAP_WGRAD_BRICK_BLOCKS"); target = q->Cb <= 16 ? 512 : (eb2 && atol(eb2) > 0 ? atol(eb2) : 256); }      // 16-wide B tiles leave LDS for two bricks per CU (3D 16->16 at 112x112x80: 88 / 66 / 85 us with 256 / 512 / 768 blocks)
     else if (q->KC == 16) target = d3 ? 512 : 768;
     else if (!d3 && (p->na == 2 || q->Ca <= 32)) target = 512;
     long ns = target / pairs;
