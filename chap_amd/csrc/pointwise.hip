@@ -729,10 +729,11 @@ static int act_bwd_blocks(const chap_act_bwd_params* p) {
     const long npix = (long)p->N * p->D * p->H * p->W;
     const int ppb = 256 / (p->r.C / 8);
     long b = (npix + ppb - 1) / ppb;
-    // 4 blocks per CU: swept on the whole iteration (512 / 1024 / 2048 / 4096 / 8192 blocks -> 7.59 / 7.39 / 7.58 / 8.07 / 8.01 ms per
-    // 2D step): more blocks only add atomics and take CUs from the kernels of the other streams
+    // 2 blocks per CU, swept on the whole iteration (round 2, final tree: 256 / 384 / 512 / 640 / 768 / 1024 blocks -> 7.36 / 7.28 / 7.28 / 7.31 /
+    // 7.38 / 7.41 ms per 2D step, 3D 16.80-16.87 for all): more blocks add partial rows to total and take CUs from the kernels of the
+    // other streams
     static long cap = 0;
-    if (!cap) { const char* e = getenv("CHAP_ACTBWD_BLOCKS"); cap = (e && atol(e) > 0 && atol(e) <= CHAP_ACT_BWD_SLOTS) ? atol(e) : CHAP_ACT_BWD_SLOTS; }      // lab knob
+    if (!cap) { const char* e = getenv("CHAP_ACTBWD_BLOCKS"); cap = (e && atol(e) > 0 && atol(e) <= CHAP_ACT_BWD_SLOTS) ? atol(e) : 512; }      // lab knob
     return (int)(b < cap ? b : cap);          // one partial row per block
 }
 extern "C" int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream) {
