@@ -1,5 +1,6 @@
 // chap_wgrad: split selection, workspace sizing, launch, deterministic slab reduction.
 #include <cstdlib>
+#include <cstdio>
 #include "common.h"
 
 int chap_wgrad_launch_bf16(const chap_wgrad_params* p, int KC, int brick, float* ws, float* ws_db, int nsplit, int Ca, int Cb, hipStream_t s);
@@ -47,7 +48,17 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     else if (p->ksize == 2) target = 256;
     else if (q->brick) { const char* eb2 = getenv("CHAP_WGRAD_BRICK_BLOCKS"); target = q->Cb <= 16 ? 512 : (eb2 && atol(eb2) > 0 ? atol(eb2) : 256); }      // 16-wide B tiles leave LDS for two bricks per CU (3D 16->16 at 112x112x80: 88 / 66 / 85 us with 256 / 512 / 768 blocks)
     else if (q->KC == 16) target = d3 ? 512 : 768;
-    else if (!d3 && (p->na == 2 || q->Ca <= 32)) target = 512;
+    // (the stand-alone timings above also favoured 512 blocks for the 2D two-source / 32-channel layers; on the whole iteration the default
+    //  256 is better -- CHAP_WGRAD_TARGETS sweep, final tree: 768,512,256 -> 7.25 ms, 768,256,256 -> 7.16 ms per 2D step)
+    {   // lab knob: CHAP_WGRAD_TARGETS="a,b,c" = split targets of (2D 16-channel chunks, 2D two-source / <= 32 channels, everything else k3/k1)
+        const char* et = getenv("CHAP_WGRAD_TARGETS");
+        long ta = 0, tb = 0, tc = 0;
+        if (et && !(env && atol(env) > 0) && sscanf(et, "%ld,%ld,%ld", &ta, &tb, &tc) == 3 && p->ksize != 2 && !q->brick) {
+            if (q->KC == 16) { if (!d3 && ta > 0) target = ta; }
+            else if (!d3 && (p->na == 2 || q->Ca <= 32)) { if (tb > 0) target = tb; }      // (the class that used to have its own default)
+            else if (tc > 0) target = tc;
+        }
+    }
     long ns = target / pairs;
     if (ns < 1) ns = 1;
     if (ns > q->ntiles) ns = q->ntiles;
