@@ -51,7 +51,7 @@ __global__ void perturb_kernel(const chap_axpy_params P) {
 }
 extern "C" int chap_perturb(const chap_axpy_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->x && p->d && p->out, "chap_perturb: null argument");
-    const int nb = (int)((p->n + 255) / 256 < 2048 ? (p->n + 255) / 256 : 2048);
+    const int nb = chap_blocks(p->n, 2048);
     hipLaunchKernelGGL(perturb_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_perturb");
     return CHAP_OK;
@@ -72,7 +72,7 @@ __global__ void rand_kernel(const chap_rand_params P) {
 }
 extern "C" int chap_rand_uniform(const chap_rand_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->out, "chap_rand_uniform: null argument");
-    const int nb = (int)((p->n + 255) / 256 < 2048 ? (p->n + 255) / 256 : 2048);
+    const int nb = chap_blocks(p->n, 2048);
     hipLaunchKernelGGL(rand_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_rand_uniform");
     return CHAP_OK;
@@ -84,7 +84,7 @@ __global__ void keepmask_kernel(const chap_keepmask_params P) {
 }
 extern "C" int chap_keep_mask(const chap_keepmask_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->keep, "chap_keep_mask: null argument");
-    const int nb = (int)((p->n + 255) / 256 < 4096 ? (p->n + 255) / 256 : 4096);
+    const int nb = chap_blocks(p->n, 4096);
     hipLaunchKernelGGL(keepmask_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_keep_mask");
     return CHAP_OK;
@@ -119,7 +119,7 @@ extern "C" int chap_box_mix(const chap_boxmix_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->a && p->b && p->out && p->box, "chap_box_mix: null argument");
     const int D = p->D > 1 ? p->D : 1;
     const long total = (long)p->N * D * p->H * p->W;
-    const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    const int nb = chap_blocks(total, 2048);
     if (p->is_i64) hipLaunchKernelGGL(boxmix_kernel<int64_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const int64_t*)p->a, (const int64_t*)p->b, (int64_t*)p->out, p->box, p->N, D, p->H, p->W);
     else hipLaunchKernelGGL(boxmix_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const float*)p->a, (const float*)p->b, (float*)p->out, p->box, p->N, D, p->H, p->W);
     CHAP_LAUNCH_CHECK("chap_box_mix");
@@ -137,7 +137,7 @@ extern "C" int chap_box_mask(const chap_boxmask_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->mask && p->box, "chap_box_mask: null argument");
     const int D = p->D > 1 ? p->D : 1;
     const long total = (long)p->N * D * p->H * p->W;
-    const int nb = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    const int nb = chap_blocks(total, 2048);
     hipLaunchKernelGGL(boxmask_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p, D);
     CHAP_LAUNCH_CHECK("chap_box_mask");
     return CHAP_OK;
@@ -241,7 +241,7 @@ extern "C" int chap_sgd_step(const chap_sgd_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->param && p->grad && p->mom && p->lr && p->n > 0, "chap_sgd_step: bad argument");
     CHAP_CHECK_ARG(((uintptr_t)p->param | (uintptr_t)p->grad | (uintptr_t)p->mom) % 16 == 0, "chap_sgd_step: buffers must be 16-byte aligned");
     const long n4 = p->n / 4;
-    const int nb = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    const int nb = chap_blocks(n4, 2048);
     hipLaunchKernelGGL(sgd_kernel, dim3(nb > 0 ? nb : 1), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_sgd_step");
     return CHAP_OK;

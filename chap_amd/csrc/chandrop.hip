@@ -179,7 +179,7 @@ extern "C" int chap_fold_perturbed(const chap_fold_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->g && p->out && p->B > 0 && p->U >= 0 && p->U <= p->B && p->pix_per_sample > 0, "chap_fold_perturbed: bad argument");
     CHAP_CHECK_ARG(p->C % 8 == 0 && p->ld % 8 == 0 && p->coff % 8 == 0 && p->coff + p->C <= p->ld, "chap_fold_perturbed: C=%d ld=%d coff=%d must be multiples of 8", p->C, p->ld, p->coff);
     const long total = (long)p->B * p->pix_per_sample * (p->C / 8);
-    const int blocks = (int)(cdiv(total, 256) < 2048 ? cdiv(total, 256) : 2048);
+    const int blocks = chap_blocks(total, 2048);
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(fold_perturbed_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(fold_perturbed_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_fold_perturbed");

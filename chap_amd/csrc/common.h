@@ -1,5 +1,6 @@
 // Shared device helpers for libchap_hip.so (gfx950 only: wave64, MFMA, 160 KiB LDS).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -135,3 +136,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Grid of a grid-stride streaming kernel: ceil(units / 256) blocks, capped.  CHAP_GRID_SCALE (lab knob, per cent) scales every cap.
+static inline int chap_blocks(long units, long cap) {
+    static int scale = -1;
+    if (scale < 0) { const char* e = getenv("CHAP_GRID_SCALE"); scale = (e && atoi(e) > 0) ? atoi(e) : 100; }
+    long c = cap * scale / 100;
+    if (c < 64) c = 64;
+    const long b = (units + 255) / 256;
+    return (int)(b < c ? (b > 0 ? b : 1) : c);
+}

@@ -335,7 +335,7 @@ extern "C" int chap_act_pool2(const chap_pool_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->r.ptr && p->out, "chap_act_pool2: null argument");
     CHAP_CHECK_ARG(p->r.C % 8 == 0 && p->H % 2 == 0 && p->W % 2 == 0 && (p->D <= 1 || p->D % 2 == 0), "chap_act_pool2: C%%8, even dims required");
     const long total = (long)p->N * (p->D > 1 ? p->D / 2 : 1) * (p->H / 2) * (p->W / 2) * (p->r.C / 8);
-    const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+    const int blocks = chap_blocks(total, 4096);
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(act_pool2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(act_pool2_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_act_pool2");
@@ -457,7 +457,7 @@ extern "C" int chap_upsample2x(const chap_upsample_params* p, void* stream) {
     const bool d3 = p->dims == 3;
     if (p->H >= 2 && p->W >= 2 && (!d3 || p->D >= 2)) {
         const long cells = (long)p->N * (d3 ? p->D - 1 : p->D) * (p->H - 1) * (p->W - 1) * (p->r.C / 8);
-        const int blocks = (int)(cdiv(cells, 256) < 16384 ? cdiv(cells, 256) : 16384);
+        const int blocks = chap_blocks(cells, 16384);
         hipStream_t s = (hipStream_t)stream;
         if (p->dtype == CHAP_BF16) { if (d3) hipLaunchKernelGGL((upsample2x_cell_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, s, *p); else hipLaunchKernelGGL((upsample2x_cell_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, s, *p); }
         else { if (d3) hipLaunchKernelGGL((upsample2x_cell_kernel<float, true>), dim3(blocks), dim3(256), 0, s, *p); else hipLaunchKernelGGL((upsample2x_cell_kernel<float, false>), dim3(blocks), dim3(256), 0, s, *p); }
@@ -465,7 +465,7 @@ extern "C" int chap_upsample2x(const chap_upsample_params* p, void* stream) {
         return CHAP_OK;
     }
     const long total = (long)p->N * (p->dims == 3 ? 2 * p->D : p->D) * 2 * p->H * 2 * p->W * (p->r.C / 8);
-    const int blocks = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+    const int blocks = chap_blocks(total, 8192);
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(upsample2x_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_upsample2x");
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const chap_upsample
 extern "C" int chap_upsample2x_bwd(const chap_upsample_bwd_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->g && p->out && p->C % 8 == 0 && p->g_ld % 8 == 0 && p->g_coff % 8 == 0, "chap_upsample2x_bwd: bad argument");
     const long total = (long)p->N * p->D * p->H * p->W * (p->C / 8);
-    const int blocks = (int)(cdiv(total, 256) < 8192 ? cdiv(total, 256) : 8192);
+    const int blocks = chap_blocks(total, 8192);
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_upsample2x_bwd");
@@ -792,14 +792,14 @@ extern "C" int chap_planar_to_cl(const chap_planar_to_cl_params* p, void* stream
     const int Cp = p->Cpad > p->C ? p->Cpad : p->C;
     if (Cp % 8 == 0 && p->out_ld % 8 == 0 && p->out_coff % 8 == 0) {
         const long total = (long)p->N * p->P * (Cp / 8);
-        const int blocks = (int)(cdiv(total, 256) < 16384 ? cdiv(total, 256) : 16384);
+        const int blocks = chap_blocks(total, 16384);
         if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(planar_to_cl8_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
         else hipLaunchKernelGGL(planar_to_cl8_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
         CHAP_LAUNCH_CHECK("chap_planar_to_cl");
         return CHAP_OK;
     }
     const long total = (long)p->N * p->P * Cp;
-    const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+    const int blocks = chap_blocks(total, 4096);
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(planar_to_cl_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(planar_to_cl_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_planar_to_cl");
@@ -820,7 +820,7 @@ __global__ void cl_to_planar_kernel(const chap_cl_to_planar_params P) {
 extern "C" int chap_cl_to_planar(const chap_cl_to_planar_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->r.ptr && p->out, "chap_cl_to_planar: null argument");
     const long total = (long)p->N * p->P * p->r.C;
-    const int blocks = (int)(cdiv(total, 256) < 4096 ? cdiv(total, 256) : 4096);
+    const int blocks = chap_blocks(total, 4096);
     if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(cl_to_planar_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     else hipLaunchKernelGGL(cl_to_planar_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_cl_to_planar");
