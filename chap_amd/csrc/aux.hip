@@ -172,17 +172,35 @@ __global__ __launch_bounds__(1024) void diffmask_select_kernel(const chap_diffma
         __syncthreads();
         const unsigned prefix = s_prefix;
         const unsigned himask = shift == 24 ? 0u : ~((1u << (shift + 8)) - 1u);
-        for (int i = threadIdx.x; i < M; i += 1024) {
-            float f = v[i]; if (f < 0.f) f = 0.f;
+        const int Mpad = (M + 63) & ~63;                       // whole waves go through the loop (ballots)
+        for (int i = threadIdx.x; i < Mpad; i += 1024) {
+            float f = i < M ? v[i] : 0.f; if (f < 0.f) f = 0.f;
             const unsigned u = __float_as_uint(f);
-            if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+            const bool hit = i < M && (u & himask) == prefix;
+            const unsigned bin = (u >> shift) & 255u;
+            if (shift == 24) {
+                // first pass: sign + exponent bits -- nearly every value falls into one or two bins, i.e. one LDS word takes every
+                // increment of the block.  One increment per distinct bin of a wave instead (a leader adds the group's count).
+                unsigned long long todo = __ballot(hit);
+                while (todo) {
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const unsigned lb = __shfl(bin, leader, 64);
+                    const unsigned long long same = __ballot(hit && bin == lb) & todo;
+                    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
+                    todo &= ~same;
+                }
+            } else if (hit) atomicAdd(&hist[bin], 1u);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int rem = s_rem, b = 255;
-            for (; b > 0; --b) { if ((int)hist[b] >= rem) break; rem -= (int)hist[b]; }
-            s_rem = rem;
-            s_prefix = prefix | ((unsigned)b << shift);
+        // the k-th largest lies in the bin t with  (values in bins above t) < rem <= (values in bins above t) + hist[t]: exactly one
+        // of the 256 threads finds it (a single thread walking the bins cost 7 us per pass)
+        const int rem0 = s_rem;
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const int t = threadIdx.x;
+            int above = 0;
+            for (int b = t + 1; b < 256; ++b) above += (int)hist[b];
+            if (above < rem0 && rem0 <= above + (int)hist[t]) { s_rem = rem0 - above; s_prefix = prefix | ((unsigned)t << shift); }
         }
         __syncthreads();
     }
