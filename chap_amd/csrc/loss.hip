@@ -13,6 +13,32 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // Called by all 256 threads of ONE block; `tot` (shared, rl floats) receives the totals too.  Ends with a barrier.
 __device__ __forceinline__ void sum_partial_rows(float* ws, int nrows, int rl, float* tot) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (rl <= 32 && nrows <= CHAP_LOSS_SLOTS) {
+        // every load of the block first (a wave's columns wave, wave + 4, ..: at most 8, a lane's rows lane, lane + 64, ..: at most 8),
+        // then the sums in the same fixed order as the loop below -- the kernel is one dependent round trip instead of eight
+        constexpr int NR = 8, NB = CHAP_LOSS_SLOTS / 64;
+        float v[NR][NB];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = wave + 4 * r;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int b = lane + 64 * k;
+                v[r][k] = ws[(long)(1 + (b < nrows ? b : 0)) * rl + (i < rl ? i : 0)];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = wave + 4 * r;
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) t += (lane + 64 * k < nrows) ? (double)v[r][k] : 0.0;
+            t = wave_sum_f64(t);
+            if (lane == 0 && i < rl) { tot[i] = (float)t; ws[i] = (float)t; }
+        }
+        __syncthreads();
+        return;
+    }
     for (int i = wave; i < rl; i += 4) {
         double t = 0.0;
         for (int b = lane; b < nrows; b += 64) t += (double)ws[(long)(1 + b) * rl + i];
