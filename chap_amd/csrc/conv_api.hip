@@ -21,7 +21,16 @@ static conv_blocking blocking_for(int Ck, int taps, int Cout_logical, int dtype)
     // 3D 3x3x3 with <= 32 input channels (the large-volume levels): chunks of 16 keep the 6x6x18 halo brick at 41 KB
     // (two buffers), which leaves LDS for the staged weights and registers for a pipelined tap loop: 32->16 at
     // 80x112x112 runs 1.9x faster than with KC = 32 (weights streamed from L2 inside the tap loop)
-    if (taps == 27 && Ck == 32) b.KC = 16;
+    {
+        // 3D 3x3x3: 16-channel chunks for EVERY layer (round 1: only for 32 input channels, from stand-alone timings; on the whole iteration:
+        // CHAP_CONV_KC16_MAXC = 32 / 64 / 128 / 256 -> 16.18 / 16.00 / 15.49 / 15.37 ms per 3D step -- half the halo LDS per block, more
+        // blocks per CU beside the kernels of the other streams).  Lab knobs; the pack and the conv read them alike.
+        static int kc16_maxc = -1, kc16_maxc2 = -1;
+        if (kc16_maxc < 0) { const char* e = getenv("CHAP_CONV_KC16_MAXC"); kc16_maxc = (e && atoi(e) > 0) ? atoi(e) : 1 << 20; }
+        if (kc16_maxc2 < 0) { const char* e = getenv("CHAP_CONV_KC16_MAXC2D"); kc16_maxc2 = (e && atoi(e) > 0) ? atoi(e) : 0; }
+        if (taps == 27 && Ck >= 32 && Ck <= kc16_maxc) b.KC = 16;
+        if (taps == 9 && Ck >= 32 && Ck <= kc16_maxc2) b.KC = 16;
+    }
     b.GPT = b.KC / 8;
     b.NP = taps * b.GPT;
     b.STEPS = (b.NP + 3) / 4;
