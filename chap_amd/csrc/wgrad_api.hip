@@ -33,7 +33,10 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     const bool small_tile = (p->dims == 3 && p->ksize >= 2);   // 3D geometries use 4 x 16 tiles (MR = 1)
     const int TH = small_tile ? 4 : 8;
     q->ntiles = (long)p->N * (q->brick ? cdiv(p->D, 4) : p->D) * cdiv(p->H, TH) * cdiv(p->W, 16);
-    const long pairs = (long)(q->Ca / q->KC) * cdiv(q->Cb, q->Cb <= 16 ? 16 : 32);
+    static int bn16_maxc = -1;
+    if (bn16_maxc < 0) { const char* e = getenv("CHAP_WGRAD_BN16_MAXC"); bn16_maxc = (e && atoi(e) > 0) ? atoi(e) : 16; }      // lab knob (wgrad_dispatch.inc reads it alike)
+    const int bn = (q->Cb <= 16 || (q->brick && q->Cb <= bn16_maxc)) ? 16 : 32;
+    const long pairs = (long)(q->Ca / q->KC) * cdiv(q->Cb, bn);
     // Persistent, pipelined blocks.  What bounds the small-channel layers (most of the bytes) is memory-level parallelism --
     // a block keeps a few KB in flight -- so they take as many blocks as stay resident (LDS: 3 per CU with 16-channel chunks,
     // 2 with 32); their slabs are tiny (9-37 KB).  The wide layers keep about one block per CU: more splits only add slab
@@ -46,7 +49,7 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     const char* env = getenv("CHAP_WGRAD_BLOCKS");          // lab knob for those sweeps
     if (env && atol(env) > 0) target = atol(env);
     else if (p->ksize == 2) target = 256;
-    else if (q->brick) { const char* eb2 = getenv("CHAP_WGRAD_BRICK_BLOCKS"); target = q->Cb <= 16 ? 512 : (eb2 && atol(eb2) > 0 ? atol(eb2) : 256); }      // 16-wide B tiles leave LDS for two bricks per CU (3D 16->16 at 112x112x80: 88 / 66 / 85 us with 256 / 512 / 768 blocks)
+    else if (q->brick) { const char* eb2 = getenv("CHAP_WGRAD_BRICK_BLOCKS"); target = bn == 16 ? 512 : (eb2 && atol(eb2) > 0 ? atol(eb2) : 256); }      // 16-wide B tiles leave LDS for two bricks per CU (3D 16->16 at 112x112x80: 88 / 66 / 85 us with 256 / 512 / 768 blocks)
     else if (q->KC == 16) target = d3 ? 512 : 768;
     // (the stand-alone timings above also favoured 512 blocks for the 2D two-source / 32-channel layers; on the whole iteration the default
     //  256 is better -- CHAP_WGRAD_TARGETS sweep, final tree: 768,512,256 -> 7.25 ms, 768,256,256 -> 7.16 ms per 2D step)
