@@ -47,6 +47,37 @@ static int check_src(const chap_src_t& s, const char* what) {
     return CHAP_OK;
 }
 
+// The V-Net heads: 1x1x1 conv of a 16-channel lazy activation to <= 8 classes, fp32 planar logits (vnet.py:189 out_conv).  On the MFMA
+// kernel this is a 16-wide tile with 2 live columns and element stores per class (43 us at 112x112x80, N = 2); it is a stream of 32 B
+// in, 8 B out per voxel -- one thread per voxel, weights in LDS, the activation rounded to bf16 like an MFMA operand.
+template <typename T>
+__global__ __launch_bounds__(256) void conv_head1x1_kernel(const chap_conv_params P) {
+    __shared__ float w[8][16], bs[8];
+    const T* wp = (const T*)P.wpacked;
+    for (int i = threadIdx.x; i < 8 * 16; i += 256) {
+        const int nl = i >> 4, c = i & 15;
+        w[nl][c] = nl < P.Cout ? elem<T>::get(wp[(((c >> 3) * 16 + nl) << 3) + (c & 7)]) : 0.f;      // fragment order of chap_pack_weights: lane = (c/8)*16 + cout
+    }
+    if (threadIdx.x < 8) bs[threadIdx.x] = (P.bias && (int)threadIdx.x < P.Cout) ? P.bias[threadIdx.x] : 0.f;
+    __syncthreads();
+    const long npx = (long)P.D * P.H * P.W, total = (long)P.N * npx;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int n = (int)(i / npx);
+        float v[16];
+        src_load8<T>(P.src[0], n, i, 0, v);
+        src_load8<T>(P.src[0], n, i, 8, v + 8);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = elem<T>::get(elem<T>::put(v[c]));
+        float* o = (float*)P.out + (long)n * P.Cout * npx + (i - (long)n * npx);
+        for (int nl = 0; nl < P.Cout; ++nl) {
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) a = fmaf(w[nl][c], v[c], a);
+            o[(long)nl * npx] = a + bs[nl];
+        }
+    }
+}
+
 extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     CHAP_CHECK_ARG(p != nullptr, "chap_conv_fwd: null params");
     CHAP_CHECK_ARG(p->nsrc == 1 || p->nsrc == 2, "chap_conv_fwd: nsrc=%d", p->nsrc);
@@ -117,6 +148,12 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
             if (ent && atoi(ent) > 0 && atoi(ent) <= b.ntiles) NT = atoi(ent);
             if (emr && atoi(emr) > 0) MR = atoi(emr);
         }
+    }
+    if (p->dtype == CHAP_BF16 && geom == 3 && p->out_planar && p->Cout <= 8 && p->nsrc == 1 && Ck == 16 && p->src[0].C == 16 && !p->stats && p->out_mode == 0) {
+        const long total = (long)p->N * p->D * p->H * p->W;
+        hipLaunchKernelGGL(conv_head1x1_kernel<bf16_t>, dim3(chap_blocks(total, 4096)), dim3(256), 0, (hipStream_t)stream, *p);
+        CHAP_LAUNCH_CHECK("chap_conv_fwd(head)");
+        return CHAP_OK;
     }
     // ---- the deep, small 3x3(x3) layers: K-chunks side by side (conv_kpar.h) instead of one after the other
     if (p->dtype == CHAP_BF16 && (geom == 1 || geom == 2) && p->out_mode == 0 && !p->out_planar && (p->Cout & 3) == 0 &&
