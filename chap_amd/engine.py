@@ -175,7 +175,7 @@ class Executor:
             return op.cout * (2 ** dims) if op.kind == "deconv" else op.cout
         nbn = sum(op.cout for op in prog.ops if op.bn or op.inorm)
         nstat = sum(ops.stats_size(clog(op)) for op in prog.ops if (op.bn and train) or op.inorm)
-        arena = torch.empty(nstat + nbn * 5, dtype=torch.float32, device=dev)
+        arena = torch.empty(nstat + nbn * 4, dtype=torch.float32, device=dev)
         apos = 0
         # shift of the statistics' moments (sum(x - c), sum((x - c)^2)): a pass-private snapshot of the running means, so
         # that the conv and its finalize see the same c whatever another stream's pass does to the running statistics
@@ -184,7 +184,9 @@ class Executor:
         if rm_flat is not None:
             shift_snap = self.m._shift_hold                   # the iteration's snapshot (ChapNet.hold_stat_shift), if one is held
             if shift_snap is None:
-                shift_snap = arena[nstat + nbn * 4:nstat + nbn * 4 + rm_flat.numel()]
+                # sized by the module's running-mean buffer, not by the program's BN channel count (a module may own BatchNorm
+                # layers that this program never runs)
+                shift_snap = torch.empty_like(rm_flat)
                 shift_snap.copy_(rm_flat)
 
         def take(n):

@@ -9,11 +9,12 @@ backward (+ fp_loss) = phase V; they are produced concurrently on two streams) a
 contiguous fp32 buffer, and only their SUM matters to the optimizer (the fused SGD consumes
 (bucket0 + bucket1) * (1/world)).  Two schedules:
 
-* overlap (default, what north_star names): phase B finishes long before the VAT chain -- its bucket is all-reduced on
+* overlap (`overlap=True`; what north_star names; EXPERIMENTAL until the two-rank GPU test has run on a >= 2 GPU machine --
+  measured slower than fold on a 1-rank group): phase B finishes long before the VAT chain -- its bucket is all-reduced on
   phase B's stream as soon as it is final (`start_first`), BESIDE the VAT forward/backward passes; bucket 1 follows
   when the chain is done (`start`).  Exposed on the critical path: the all-reduce of bucket 1 only (10.3 MB 2D / 49.4 MB
   3D), with twice those bytes on the links in total.
-* fold (overlap=False): bucket 1 is folded into bucket 0 (one axpy kernel + a memset) at the end and that half alone is
+* fold (the default, what bench.py and DESIGN.md use): bucket 1 is folded into bucket 0 (one axpy kernel + a memset) at the end and that half alone is
   all-reduced: the same exposed bytes, half the link traffic, nothing overlapped.
 
 With HIP-graph replay RCCL is never captured: the iteration is [graph A] -> [graph B on the side stream | graph V] with
@@ -23,7 +24,7 @@ import torch
 
 
 class DataParallelSync:
-    def __init__(self, both_buckets, dist, group=None, overlap=True):
+    def __init__(self, both_buckets, dist, group=None, overlap=False):
         self.buf, self.dist, self.group, self.overlap = both_buckets, dist, group, overlap
         self.work, self.work0 = None, None
 

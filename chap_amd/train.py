@@ -538,7 +538,10 @@ class ChapStep:
             self.load_state_dict(snap)
             torch.cuda.synchronize()
         self.model._rng.reset_counter()
-        self.prepare()
+        np_state = np.random.get_state()
+        self.prepare()                          # the schedule block must hold valid values while the graph is being captured ...
+        if restore:
+            np.random.set_state(np_state)       # ... but its BCP-box draw is not an iteration's: capture() leaves the numpy stream untouched
         # the four-graph form only when bucket 0 is to be all-reduced beside the VAT chain; the fold schedule exchanges once, at the
         # end: [compute graph] -> all-reduce -> [optimizer graph] keeps pass B and the VAT chain as forked branches of ONE graph
         if (self.grad_sync is not None and getattr(self.grad_sync, "overlap", False) and type(self)._iteration is ChapStep._iteration

@@ -56,7 +56,21 @@ def train(args, snapshot_path):
         vi, vl = synthetic_batch(a["seed"] + 4242, 8, 0, *a["image_size"], a["num_classes"])
         val = [(vi[:, 0].unsqueeze(0), vl.unsqueeze(0))]
     best, captured = 0.0, False
-    for sampled_batch in loader:                                                 # :301-302
+
+    def batches():
+        """The epoch loop of the reference (:299-302, 459-463): `max_epoch = max_iterations // len(trainloader) + 1` passes
+        over the loader, i.e. a finite loader is re-iterated until max_iterations is reached (the generator of the synthetic
+        stand-in never ends; a one-shot iterator that runs dry ends the run, loudly)."""
+        while True:
+            n = 0
+            for b in loader:
+                n += 1
+                yield b
+            if n == 0:
+                raise RuntimeError("chap_amd.train: the train loader yielded no batch (exhausted one-shot iterator or empty dataset) "
+                                   "at iteration %d of %d" % (step.iter_num, a["max_iterations"]))
+
+    for sampled_batch in batches():
         volume_batch = sampled_batch["image"].to(device, non_blocking=True)
         label_batch = sampled_batch["label"].to(device, non_blocking=True)
         if a["use_graph"]:

@@ -179,3 +179,37 @@ def test_oracle_sgd_step_is_torch_optim_sgd():
             pg["lr"] = 0.01 * (1.0 - (it + 1) / 30000) ** 0.9           # train_ours_2D.py:387-389
         for a, b in zip(p_ref, p_or):
             assert torch.allclose(a.detach(), b, rtol=2e-6, atol=1e-7), (it, float((a.detach() - b).abs().max()))     # same formula; fused-multiply order differs
+
+
+def test_train_loop_reiterates_a_finite_loader_until_max_iterations(tmp_path, monkeypatch):
+    """train() wraps the loader in the reference's epoch loop (code/train_ours_2D.py:299-302: max_epoch = max_iterations //
+    len(trainloader) + 1 passes, break at max_iterations, :459-463): a 3-batch list loader and max_iterations = 7 gives 7
+    iterations over 3 epochs, not 3.  Host logic only: the device step is a stub."""
+    from chap_amd import train_ours_2D as T
+    seen = []
+
+    class FakeStep:
+        def __init__(self, model, a):
+            self.iter_num = 0
+
+        def step(self, v, l):
+            seen.append(int(v[0, 0, 0, 0]))
+            self.iter_num += 1
+            return {"mix_losses": [torch.zeros(3)], "vat_loss": torch.zeros(1)}
+
+    class FakeModel(torch.nn.Module):
+        def set_compute_dtype(self, d):
+            return self
+
+    monkeypatch.setattr(T, "ChapStep", FakeStep)
+    monkeypatch.setattr(T, "net_factory", lambda **kw: FakeModel())
+    monkeypatch.setattr(torch.Tensor, "to", lambda self, *a, **k: self)
+    monkeypatch.setattr(torch, "device", lambda *a, **k: "cpu")
+    loader = [{"image": torch.full((2, 1, 4, 4), float(i)), "label": torch.zeros(2, 4, 4, dtype=torch.int64)} for i in range(3)]
+    T.train(dict(trainloader=loader, val_volumes=[], max_iterations=7, val_interval=1000, use_graph=False, image_size=[4, 4]), str(tmp_path / "run"))
+    assert seen == [0, 1, 2, 0, 1, 2, 0]
+    # a one-shot iterator that runs dry ends the run loudly instead of returning a half-trained model
+    seen.clear()
+    with pytest.raises(RuntimeError, match="yielded no batch"):
+        T.train(dict(trainloader=iter(loader), val_volumes=[], max_iterations=7, val_interval=1000, use_graph=False, image_size=[4, 4]), str(tmp_path / "run2"))
+    assert seen == [0, 1, 2]

@@ -46,3 +46,39 @@ def test_two_bucket_allreduce_gloo(tmp_path, overlap):
     for r in range(world):
         got = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert torch.allclose(got, want, atol=1e-6)
+
+
+def _bench(*argv, timeout=120):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + [str(a) for a in argv], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_self_launch_plumbing_dry_run():
+    """`python bench.py --gpus N` without a launcher (bench.py:self_launch): N fresh rank processes are started before anything
+    touches a GPU, rendezvous on 127.0.0.1, barrier / timed region / barrier with the MAX over ranks, and rank 0's ONE JSON line is
+    forwarded on stdout -- rehearsed on the CPU (gloo, --dry-run: no GPU, no model)."""
+    import json
+    port = 29200 + os.getpid() % 500
+    r = _bench("--gpus", 2, "--dry-run", "--steps", 4, "--master-port", port)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert d["ms_per_step"] >= 2.0          # the slowest rank (rank 1 sleeps 2 ms per step) sets the time: MAX over ranks
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    """A rank other than 0 dying early (port in use, RCCL init error) must not leave rank 0 hanging in the rendezvous: the launcher
+    watches all children, stops the others and exits with the failing rank's code."""
+    import time
+    port = 29700 + os.getpid() % 250
+    t0 = time.time()
+    r = _bench("--gpus", 3, "--dry-run", "--steps", 2, "--dry-run-fail-rank", 2, "--master-port", port, "--launch-timeout", 90)
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 60
+    assert "rank 2 exited with code 3" in r.stderr
+    assert r.stdout.strip() == ""
