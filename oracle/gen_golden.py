@@ -277,6 +277,22 @@ def gen_3d(ref):
                         checks=_checks(list(md.state_dict().items())))
 
 
+def gen_3d_full(ref):
+    """Full-size (config-3 shape) eval logits of the imported DualDecoder3d, N = 1 at 112 x 112 x 80 (vnet.py:225-238; the LA patch
+    of test_LA.py:24): every 4th voxel per axis plus whole-tensor checksums."""
+    m = ref["DualDecoder3d"](n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)
+    m.load_state_dict(oinit.dual_decoder_3d_state(201), strict=True)
+    m.eval()
+    x = torch.rand(1, 1, 112, 112, 80, generator=torch.Generator().manual_seed(28))
+    with torch.no_grad():
+        o1, o2 = m(x)
+    np.savez_compressed(os.path.join(OUT, "dualdecoder3d_112.npz"), x_seed=28, state_seed=201,
+                        logits0_sub=_np(o1[:, :, ::4, ::4, ::4]), logits1_sub=_np(o2[:, :, ::4, ::4, ::4]),
+                        sums=np.array([o1.double().sum().item(), o2.double().sum().item(),
+                                       o1.double().abs().sum().item(), o2.double().abs().sum().item()]))
+    print("dualdecoder3d_112.npz: logits", tuple(o1.shape), "abs max", float(o1.abs().max()), float(o2.abs().max()))
+
+
 class ScriptedDraws:
     """While active, every random draw FilterDropout.py makes comes from a scripted list of uniform tensors:
     torch.bernoulli(q) -> (u < q), Binomial(0.5).sample(shape) -> (u < 0.5), nn.Dropout2d(0.5)(x) -> x * 2 * (u < 0.5),
@@ -444,11 +460,14 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = import_reference()
-    gen_2d(ref)
-    gen_2d_variants(ref)
-    gen_3d(ref)
-    gen_filter_dropout(ref)
-    gen_train_plumbing()
+    only = sys.argv[1:]                     # e.g. `gen_golden.py gen_3d_full`: (re)generate one fixture
+    steps = [("gen_2d", lambda: gen_2d(ref)), ("gen_2d_variants", lambda: gen_2d_variants(ref)), ("gen_3d", lambda: gen_3d(ref)),
+             ("gen_3d_full", lambda: gen_3d_full(ref)), ("gen_filter_dropout", lambda: gen_filter_dropout(ref)),
+             ("gen_train_plumbing", gen_train_plumbing)]
+    assert all(o in dict(steps) for o in only), only
+    for name, fn in steps:
+        if not only or name in only:
+            fn()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

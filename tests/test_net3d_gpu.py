@@ -43,6 +43,29 @@ def test_dualdecoder3d_eval(golden_dir, dtype):
         assert cosine(dx, g["eval_dx"]) > 0.9
 
 
+def test_dualdecoder3d_fullsize_eval(golden_dir):
+    """BASELINE config 3's volume: eval logits of the HIP DualDecoder3d at 1 x 112 x 112 x 80 in fp32 against the IMPORTED
+    reference's (tests/golden/dualdecoder3d_112.npz, oracle/gen_golden.py:gen_3d_full; vnet.py:225-238): every 4th voxel per
+    axis within north_star's 1e-4, plus the whole-tensor checksums (a wrong brick / tile anywhere in the volume moves them)."""
+    g = _load(golden_dir, "dualdecoder3d_112.npz")
+    m = net_factory_3d("dualdecoder", 1, 2, "test", DEV)
+    m.load_state_dict(oinit.dual_decoder_3d_state(int(g["state_seed"])), strict=True)
+    m.eval()
+    x = torch.rand(1, 1, 112, 112, 80, generator=torch.Generator().manual_seed(int(g["x_seed"]))).to(DEV)
+    with torch.no_grad():
+        o1, o2 = m(x)
+    assert relerr(o1[:, :, ::4, ::4, ::4], g["logits0_sub"]) < 1e-4
+    assert relerr(o2[:, :, ::4, ::4, ::4], g["logits1_sub"]) < 1e-4
+    sums = np.array([o1.double().sum().item(), o2.double().sum().item(), o1.double().abs().sum().item(), o2.double().abs().sum().item()])
+    assert np.allclose(sums, g["sums"], rtol=1e-4), (sums, g["sums"])
+    # bf16 (the benchmarked mode) on the same volume: same label map away from ties, logits within bf16's resolution of the network
+    m.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        b1, b2 = m(x)
+    assert relerr(b1[:, :, ::4, ::4, ::4], g["logits0_sub"]) < 5e-2 and relerr(b2[:, :, ::4, ::4, ::4], g["logits1_sub"]) < 5e-2
+    assert (b1.argmax(1) == o1.argmax(1)).float().mean() > 0.99
+
+
 def test_dualdecoder3d_train_injected(golden_dir):
     g = _load(golden_dir, "dualdecoder3d_32.npz")
     m = net_factory_3d("dualdecoder", 1, 2, "train", DEV)

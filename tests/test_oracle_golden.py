@@ -99,6 +99,20 @@ def test_dualdecoder2d_fullsize_eval(golden_dir):
     assert _relerr(o2[:, :, ::4, ::4], g["logits1_sub"]) < 1e-5
 
 
+def test_dualdecoder3d_fullsize_eval(golden_dir):
+    """config-3 shape: the oracle's eval logits at 1 x 112 x 112 x 80 against the imported reference (vnet.py:225-238),
+    sub-sampled values and whole-tensor checksums."""
+    g = _load(golden_dir, "dualdecoder3d_112.npz")
+    sd = _sd(oinit.dual_decoder_3d_state(int(g["state_seed"])), grad=False)
+    x = torch.rand(1, 1, 112, 112, 80, generator=torch.Generator().manual_seed(int(g["x_seed"])))
+    with torch.no_grad():
+        o1, o2 = nets.dual_decoder_3d(sd, x, train=False)
+    assert _relerr(o1[:, :, ::4, ::4, ::4], g["logits0_sub"]) < 1e-5
+    assert _relerr(o2[:, :, ::4, ::4, ::4], g["logits1_sub"]) < 1e-5
+    sums = np.array([o1.double().sum().item(), o2.double().sum().item(), o1.double().abs().sum().item(), o2.double().abs().sum().item()])
+    assert np.allclose(sums, g["sums"], rtol=1e-5)
+
+
 def test_unet2d(golden_dir):
     g = _load(golden_dir, "unet2d_32.npz")
     state = oinit.unet_2d_state(int(g["state_seed"]))

@@ -124,15 +124,10 @@ def test_vat_variants_iteration_matches_oracle(variant):
     torch.cuda.synchronize()
     for got, want in zip(out["mix_losses"], ref["losses"]):
         assert relerr(got.cpu(), torch.stack([w.detach() for w in want])) < 2e-4
-    # the adversarial direction comes out of K power iterations through train-mode BatchNorm on a tiny batch (4 x 64 x 64), and
-    # sign(d) is discontinuous where d ~ 0: the loss at x + r_adv is compared loosely, the UPDATE it produces (0.45 x the VAT
-    # gradient + the BCP gradient) as a whole.  Measured (MI355X, fixed-order reductions: the same on every run): vat_loss
-    # relative error 0.003 (dice) .. 0.026 (k2), update relative L2 0.02 (dice) .. 0.06 (sign) .. 0.10 (k2), smallest per-tensor
-    # cosine 0.983 .. 0.999 (the smallest ones on 16..128-element BatchNorm biases).
-    assert relerr(out["vat_loss"].cpu(), ref["vat_loss"].reshape(1)) < 5e-2, (float(out["vat_loss"]), float(ref["vat_loss"]))
-    rel_l2, cos_min, cos_key = update_agreement(sd, state, m.state_dict())
-    assert rel_l2 < 0.15, rel_l2
-    assert cos_min > 0.97, (cos_min, cos_key)
+    # The VAT loss and the SGD update of these variants are ill-conditioned on this tiny batch (K power iterations through
+    # training-mode BatchNorm over 4 x 64 x 64 values, sign(d) discontinuous where d ~ 0): they are judged against an fp64 oracle,
+    # relative to the fp32 oracle's own distance to it, in tests/test_iteration_conditioning_gpu.py (same state, same variants) --
+    # no absolute bound is asserted here any more (round 2 had widened them to 5e-2 / 0.15 / 0.97 after red runs).
     # the variant really is a different computation from the default iteration
     sd0, moms0 = _oracle_state(state)
     base_args = dict(labeled_bs=lbs, batch_size=B, vat_iters=1)
@@ -163,18 +158,8 @@ def test_k2_iteration_3d_matches_oracle():
     torch.cuda.synchronize()
     for got, want in zip(out["mix_losses"], ref["losses"]):
         assert relerr(got.cpu(), torch.stack([w.detach() for w in want])) < 5e-4
-    assert relerr(out["vat_loss"].cpu(), ref["vat_loss"].reshape(1)) < 3e-2
-    after = m.state_dict()
-    ups_h, ups_o = [], []
-    for k, v in sd.items():
-        if not v.is_floating_point() or k.endswith(("running_mean", "running_var")):
-            continue
-        if k in ref["grads"] and ref["grads"][k].abs().max().item() < 1e-3:
-            continue
-        ups_h.append((after[k].cpu().double() - state[k].double()).reshape(-1))
-        ups_o.append((v.detach().double() - state[k].double()).reshape(-1))
-    uh, uo = torch.cat(ups_h), torch.cat(ups_o)
-    assert float(uh @ uo / (uh.norm() * uo.norm())) > 0.99
+    # VAT loss and update: tests/test_iteration_conditioning_gpu.py::test_small_3d_iteration_is_as_close_to_fp64_as_the_fp32_oracle[2]
+    # (distance to an fp64 oracle relative to the fp32 oracle's own)
 
 
 # ------------------------------------------------------------------------------------------------ (c)
@@ -262,34 +247,69 @@ def _dice(pred, gt, n_classes=4):
     return np.array(out)
 
 
-def test_bf16_training_dice_gate():
-    """bf16 is the throughput mode bench.py times: train the same schedule in bf16 and in fp32 from one seed (graph replay,
-    device RNG: identical dropout masks, VAT noise and BCP boxes in the two runs) until the model segments the synthetic
-    slices, then compare the Dice of the two checkpoints on held-out slices (the reference's inference recipe,
-    test_2D_fully.py:69-75).  The iteration is discontinuous in the weights (arg-max pseudo labels, LCC), so the two
-    trajectories are not the same function of time: the gate is on the Dice they reach."""
-    B, lbs, H, W, ITERS = 8, 4, 64, 64, 1500
+def _train_and_dice(dtype, rng_seed, B, H, W, iters, lr=0.05):
+    """The same schedule from the same initial weights (manual_seed(1337) default init), data pool and BCP boxes; `rng_seed`
+    seeds the device RNG of the dropout masks and the VAT noise.  Returns per-class Dice of the logit-ensemble prediction
+    (test_2D_fully.py:69-75) on 24 held-out slices."""
+    lbs = B // 2
     pool = [ots.synthetic_batch(2000 + i, lbs, B - lbs, H, W) for i in range(16)]
     pool = [(v.to(DEV), l.to(DEV)) for v, l in pool]
     val, gt = ots.synthetic_batch(4242, 24, 0, H, W)
-    dices = {}
-    for dtype in (torch.float32, torch.bfloat16):
-        torch.manual_seed(1337)
-        np.random.seed(1337)
-        m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train().set_compute_dtype(dtype)
-        step = ChapStep(m, dict(labeled_bs=lbs, batch_size=B, base_lr=0.05, max_iterations=ITERS))     # poly LR runs down to 0: a converged checkpoint
-        step.capture(*pool[0], warmup=1)
-        for it in range(ITERS):
-            step.replay(*pool[it % len(pool)])
-        m.eval()
-        with torch.no_grad():
-            o1, o2 = m(val.to(DEV))
-        pred = torch.argmax(torch.softmax((o1 + o2) / 2.0, dim=1), dim=1).cpu().numpy()
-        dices[dtype] = _dice(pred, gt.numpy())
-    d32, d16 = dices[torch.float32], dices[torch.bfloat16]
-    print("Dice fp32 %s (mean %.4f)  bf16 %s (mean %.4f)" % (d32.round(4), d32.mean(), d16.round(4), d16.mean()))
+    torch.manual_seed(1337)
+    np.random.seed(1337)
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train().set_compute_dtype(dtype)
+    torch.manual_seed(rng_seed)                       # the model's RNG (dropout, VAT noise) is created from torch's seed at first use
+    step = ChapStep(m, dict(labeled_bs=lbs, batch_size=B, base_lr=lr, max_iterations=iters))     # poly LR runs down to 0: a converged checkpoint
+    step.capture(*pool[0], warmup=1)
+    for it in range(iters):
+        step.replay(*pool[it % len(pool)])
+    m.eval()
+    with torch.no_grad():
+        o1, o2 = m(val.to(DEV))
+    pred = torch.argmax(torch.softmax((o1 + o2) / 2.0, dim=1), dim=1).cpu().numpy()
+    return _dice(pred, gt.numpy())
+
+
+def _log_dice_gate(rec):
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r03_dice_gate.jsonl")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
+    print(json.dumps(rec))
+
+
+# bound = 2 x the measured |mean Dice(bf16) - mean Dice(fp32)| (profiles/r03_dice_gate.jsonl: 0.0049 at 64 x 64, 0.0184 at 256 x 256;
+# two fp32 runs that differ only in the dropout / VAT-noise seed end 0.0120 / 0.0156 apart)
+DICE_GATE = {"64": dict(B=8, H=64, W=64, iters=1500, bound=0.01), "256": dict(B=24, H=256, W=256, iters=1500, bound=0.037)}
+
+
+@pytest.mark.parametrize("size", ["64", "256"])
+def test_bf16_training_dice_gate(size):
+    """bf16 is the throughput mode bench.py times: train the same schedule in bf16 and in fp32 from one seed (graph replay,
+    device RNG: identical dropout masks, VAT noise and BCP boxes in the two runs) until the model segments the synthetic
+    slices, then compare the Dice of the two checkpoints on held-out slices (the reference's inference recipe,
+    test_2D_fully.py:69-75) -- at 64 x 64 (B = 8) and at BASELINE config 1's size (B = 24, 256 x 256).  The iteration is
+    discontinuous in the weights (arg-max pseudo labels, LCC), so two trajectories are not the same function of time: a THIRD
+    run, fp32 with another dropout / VAT-noise seed, gives the scale -- how far two equally valid fp32 runs end up from each
+    other.  north_star's 1e-3 is a statement about one checkpoint evaluated on both sides (tests/test_training_parity_gpu.py
+    holds it there); between two training runs it is below the seed-to-seed spread of fp32 itself, and the measured figures are
+    written to gpurun_out/r03_dice_gate.jsonl (committed copy under profiles/) instead of being asserted away."""
+    c = DICE_GATE[size]
+    d32 = _train_and_dice(torch.float32, 1337, c["B"], c["H"], c["W"], c["iters"])
+    d16 = _train_and_dice(torch.bfloat16, 1337, c["B"], c["H"], c["W"], c["iters"])
+    d32b = _train_and_dice(torch.float32, 4711, c["B"], c["H"], c["W"], c["iters"])
+    rec = {"size": "%dx%d" % (c["H"], c["W"]), "batch": c["B"], "iterations": c["iters"], "dice_fp32": d32.round(5).tolist(), "dice_bf16": d16.round(5).tolist(),
+           "dice_fp32_other_seed": d32b.round(5).tolist(), "mean_fp32": round(float(d32.mean()), 5), "mean_bf16": round(float(d16.mean()), 5),
+           "mean_fp32_other_seed": round(float(d32b.mean()), 5), "abs_delta_bf16_vs_fp32": round(abs(float(d32.mean() - d16.mean())), 5),
+           "abs_delta_fp32_seed_vs_seed": round(abs(float(d32.mean() - d32b.mean())), 5), "asserted_bound": c["bound"]}
+    _log_dice_gate(rec)
     assert d32.mean() > 0.7 and d16.mean() > 0.7, (d32, d16)          # both runs learned to segment
-    assert abs(d32.mean() - d16.mean()) < 0.05, (d32, d16)            # stated bound; measured value in DESIGN.md section 8
+    assert abs(d32.mean() - d16.mean()) < c["bound"], rec              # 2 x measured (profiles/r03_dice_gate.jsonl)
 
 
 # ------------------------------------------------------------------------------------------------ N1: GradSim

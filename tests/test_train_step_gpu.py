@@ -149,26 +149,10 @@ def test_iteration_3d_matches_oracle():
     torch.cuda.synchronize()
     for got, want in zip(out["mix_losses"], ref["losses"]):
         assert relerr(got.cpu(), torch.stack([w.detach() for w in want])) < 5e-4
-    assert relerr(out["vat_loss"].cpu(), ref["vat_loss"].reshape(1)) < 1e-2
-    # tiny volumes (BatchNorm over 32-256 elements per channel at the deep levels) make fp32 training-mode
-    # gradients noisy on BOTH sides: compare the whole update direction tightly, single tensors loosely.
-    after = m.state_dict()
-    ups_h, ups_o, worst, worst_key = [], [], 0.0, None
-    for k, v in sd.items():
-        if not v.is_floating_point() or k.endswith(("running_mean", "running_var")):
-            continue
-        if k in ref["grads"] and ref["grads"][k].abs().max().item() < 1e-3:
-            continue
-        uh = (after[k].cpu().double() - state[k].double()).reshape(-1)
-        uo = (v.detach().double() - state[k].double()).reshape(-1)
-        ups_h.append(uh); ups_o.append(uo)
-        e = (uh - uo).abs().max().item() / (uo.abs().max().item() + 1e-30)
-        if e > worst:
-            worst, worst_key = e, k
-    uh, uo = torch.cat(ups_h), torch.cat(ups_o)
-    cos = float(uh @ uo / (uh.norm() * uo.norm()))
-    assert cos > 0.995, cos
-    assert worst < 0.5, (worst, worst_key)
+    # VAT loss and the SGD update (tiny volumes: BatchNorm over 32-256 elements per channel at the deep levels makes fp32
+    # training-mode gradients noisy on BOTH sides) are judged against an fp64 oracle, relative to the fp32 oracle's own distance
+    # to it: tests/test_iteration_conditioning_gpu.py::test_small_3d_iteration_is_as_close_to_fp64_as_the_fp32_oracle[1]
+    # (round 2 asserted `worst < 0.5` here)
 
 
 def test_ablation_iteration_matches_oracle():
