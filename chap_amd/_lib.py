@@ -219,7 +219,7 @@ _SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParam
 _lib = None
 
 
-ABI_VERSION = 4            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
+ABI_VERSION = 5            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
 
 
 class ChapError(RuntimeError):
@@ -290,6 +290,64 @@ def pack_multi(entries_dev_ptr, n, max_total, stream):
     rc = L.chap_pack_multi(_vp(entries_dev_ptr), n, max_total, _vp(stream))
     if rc != 0:
         raise ChapError("chap_pack_multi failed (%d): %s" % (rc, L.chap_last_error().decode()))
+
+
+class group:
+    """`with group(stream) as g: ...lane 0...; g.next_lane(); ...lane 1...`: chap_group_begin / _next_lane / _end (chap_hip.h):
+    the launches of the lanes are recorded and issued together, same-shaped ones as one grid.  `enabled=False` (or one lane
+    only) makes it a no-op wrapper, which is how the executor switches grouping off (CHAP_GROUP=0)."""
+    launched = 0            # grids issued by all regions so far (diagnostics / tests)
+    held = None             # tensors allocated inside the open region (see hold())
+
+    def __init__(self, stream, enabled=True):
+        self.stream, self.enabled = stream, enabled
+
+    def __enter__(self):
+        if self.enabled:
+            group.held = []
+            L = lib()
+            L.chap_group_begin.argtypes = [_vp]
+            rc = L.chap_group_begin(_vp(self.stream))
+            if rc != 0:
+                raise ChapError("chap_group_begin failed (%d): %s" % (rc, L.chap_last_error().decode()))
+        return self
+
+    def next_lane(self):
+        if self.enabled:
+            rc = lib().chap_group_next_lane()
+            if rc != 0:
+                raise ChapError("chap_group_next_lane failed (%d): %s" % (rc, lib().chap_last_error().decode()))
+
+    def __exit__(self, et, ev, tb):
+        if self.enabled:
+            rc = lib().chap_group_end()         # also on an exception: leaves the recording state
+            group.held = None
+            if rc < 0 and et is None:
+                raise ChapError("chap_group_end failed (%d): %s" % (rc, lib().chap_last_error().decode()))
+            if rc > 0:
+                group.launched += rc
+        return False
+
+
+def hold(t):
+    """Inside a group region the lanes' kernels run CONCURRENTLY, later than the Python code that allocated their buffers: a
+    temporary that Python drops (a workspace local to a wrapper, a gradient tensor consumed by the launches of its op) would go
+    back to the caching allocator and could be handed to the NEXT lane of the same region -- two lanes of one grid writing the
+    same memory.  Every tensor allocated on this path goes through hold(): kept alive until chap_group_end has issued the launches
+    (stream order protects it from then on).  No-op outside a region."""
+    if group.held is not None:
+        group.held.append(t)
+    return t
+
+
+def hold_empty(*a, **k):
+    import torch
+    return hold(torch.empty(*a, **k))
+
+
+def hold_empty_like(*a, **k):
+    import torch
+    return hold(torch.empty_like(*a, **k))
 
 
 def call(name, params, stream):

@@ -1,6 +1,7 @@
 // Small training-loop kernels: VAT perturbation helpers, counter-based RNG, BCP box mixing,
 // spatial perturbation mask (avg-pool + per-sample top-k by radix select), fused SGD.
 #include "common.h"
+#include "launch.h"
 
 // ---- per-sample L2 normalise: (sample, slice) blocks write their sum of squares to ss[n][slice] (no atomics); every block of
 // the scale pass re-derives the sample's total from those partials in the same fixed order -> bitwise reproducible
@@ -77,7 +78,7 @@ extern "C" int chap_rand_uniform(const chap_rand_params* p, void* stream) {
     CHAP_LAUNCH_CHECK("chap_rand_uniform");
     return CHAP_OK;
 }
-__global__ void keepmask_kernel(const chap_keepmask_params P) {
+__device__ __forceinline__ void keepmask_kernel(const chap_keepmask_params& P) {
     const uint64_t seed = P.seed + (P.seed_dev ? *P.seed_dev * 0xD1342543DE82EF95ull : 0);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += (long)gridDim.x * blockDim.x)
         P.keep[i] = u01(seed, i) >= P.p ? 1 : 0;
@@ -85,20 +86,16 @@ __global__ void keepmask_kernel(const chap_keepmask_params P) {
 extern "C" int chap_keep_mask(const chap_keepmask_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->keep, "chap_keep_mask: null argument");
     const int nb = chap_blocks(p->n, 4096);
-    hipLaunchKernelGGL(keepmask_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_keep_mask");
-    return CHAP_OK;
+    return chap_launch<chap_keepmask_params, keepmask_kernel, 256>(dim3(nb), dim3(256), 0, (hipStream_t)stream, *p, "chap_keep_mask");
 }
-__global__ void chanmask_kernel(const chap_chanmask_params P) {
+__device__ __forceinline__ void chanmask_kernel(const chap_chanmask_params& P) {
     const uint64_t seed = P.seed + (P.seed_dev ? *P.seed_dev * 0xD1342543DE82EF95ull : 0);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += (long)gridDim.x * blockDim.x)
         P.mul[i] = u01(seed, i) >= P.p ? 1.f / (1.f - P.p) : 0.f;
 }
 extern "C" int chap_chan_mask(const chap_chanmask_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->mul, "chap_chan_mask: null argument");
-    hipLaunchKernelGGL(chanmask_kernel, dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_chan_mask");
-    return CHAP_OK;
+    return chap_launch<chap_chanmask_params, chanmask_kernel, 256>(dim3((unsigned)((p->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *p, "chap_chan_mask");
 }
 
 // ---- BCP box mixing (2D: box = {y0, x0, bh, bw}; 3D cuboid: box = {z0, y0, x0, bd, bh, bw}) ----------

@@ -7,6 +7,7 @@
 //                             chan_mul rows of the (B + U)-sample decoder batch  torch.cat((feat, perturb_feat))  (:86-87)
 //   chap_fold_perturbed       the adjoint of that cat: gradient of the (B + U)-sample batch -> gradient of the B samples
 #include "common.h"
+#include "launch.h"
 
 template <typename T>
 __global__ __launch_bounds__(256) void sample_channel_sum_kernel(const chap_sample_chansum_params P) {
@@ -146,7 +147,7 @@ extern "C" int chap_channel_drop(const chap_channel_drop_params* p, void* stream
 
 // out[n] = g[n] (n < B);  out[B - U + u] += mul[B + u] * g[B + u]   -- channel slice [coff, coff + C) of g (row length ld)
 template <typename T>
-__global__ __launch_bounds__(256) void fold_perturbed_kernel(const chap_fold_params P) {
+__device__ __forceinline__ void fold_perturbed_kernel(const chap_fold_params& P) {
     const int C8 = P.C / 8;
     const long per_sample = P.pix_per_sample * C8;
     const long total = (long)P.B * per_sample;
@@ -180,8 +181,6 @@ extern "C" int chap_fold_perturbed(const chap_fold_params* p, void* stream) {
     CHAP_CHECK_ARG(p->C % 8 == 0 && p->ld % 8 == 0 && p->coff % 8 == 0 && p->coff + p->C <= p->ld, "chap_fold_perturbed: C=%d ld=%d coff=%d must be multiples of 8", p->C, p->ld, p->coff);
     const long total = (long)p->B * p->pix_per_sample * (p->C / 8);
     const int blocks = chap_blocks(total, 2048);
-    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(fold_perturbed_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL(fold_perturbed_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_fold_perturbed");
-    return CHAP_OK;
+    if (p->dtype == CHAP_BF16) return chap_launch<chap_fold_params, fold_perturbed_kernel<bf16_t>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_fold_perturbed");
+    return chap_launch<chap_fold_params, fold_perturbed_kernel<float>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_fold_perturbed");
 }

@@ -13,8 +13,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 void chap_set_error(const char* fmt, ...);
 #define CHAP_CHECK_ARG(cond, ...) do { if (!(cond)) { chap_set_error(__VA_ARGS__); return CHAP_EINVAL; } } while (0)
+bool chap_group_recording();      // launch.h: true between chap_group_begin() and chap_group_end()
+// after a DIRECT launch (kernels that are not behind launch.h's trampoline): inside a group region it would have overtaken the
+// recorded launches, which is an error of the caller
 #define CHAP_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
-    chap_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return CHAP_ELAUNCH; } } while (0)
+    chap_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return CHAP_ELAUNCH; } \
+    if (chap_group_recording()) { chap_set_error("%s: not allowed between chap_group_begin() and chap_group_end()", name); return CHAP_EUNSUPPORTED; } } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {

@@ -2,6 +2,7 @@
 #include <cstdlib>
 #include <atomic>
 #include "common.h"
+#include "launch.h"
 
 int chap_conv_launch_kpar_bf16(const chap_conv_params* p, int KC, int cpar, hipStream_t s);
 #define DECL_GEOM(dt, g) int chap_conv_launch_##dt##_g##g(const chap_conv_params* p, int KC, int NT, int MR, hipStream_t s);
@@ -51,7 +52,7 @@ static int check_src(const chap_src_t& s, const char* what) {
 // kernel this is a 16-wide tile with 2 live columns and element stores per class (43 us at 112x112x80, N = 2); it is a stream of 32 B
 // in, 8 B out per voxel -- one thread per voxel, weights in LDS, the activation rounded to bf16 like an MFMA operand.
 template <typename T>
-__global__ __launch_bounds__(256) void conv_head1x1_kernel(const chap_conv_params P) {
+__device__ __forceinline__ void conv_head1x1_kernel(const chap_conv_params& P) {
     __shared__ float w[8][16], bs[8];
     const T* wp = (const T*)P.wpacked;
     for (int i = threadIdx.x; i < 8 * 16; i += 256) {
@@ -151,9 +152,7 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     }
     if (p->dtype == CHAP_BF16 && geom == 3 && p->out_planar && p->Cout <= 8 && p->nsrc == 1 && Ck == 16 && p->src[0].C == 16 && !p->stats && p->out_mode == 0) {
         const long total = (long)p->N * p->D * p->H * p->W;
-        hipLaunchKernelGGL(conv_head1x1_kernel<bf16_t>, dim3(chap_blocks(total, 4096)), dim3(256), 0, (hipStream_t)stream, *p);
-        CHAP_LAUNCH_CHECK("chap_conv_fwd(head)");
-        return CHAP_OK;
+        return chap_launch<chap_conv_params, conv_head1x1_kernel<bf16_t>, 256>(dim3(chap_blocks(total, 4096)), dim3(256), 0, (hipStream_t)stream, *p, "chap_conv_fwd(head)");
     }
     // ---- the deep, small 3x3(x3) layers: K-chunks side by side (conv_kpar.h) instead of one after the other
     if (p->dtype == CHAP_BF16 && (geom == 1 || geom == 2) && p->out_mode == 0 && !p->out_planar && (p->Cout & 3) == 0 &&
@@ -268,6 +267,7 @@ extern "C" int chap_pack_describe(const chap_pack_params* p, chap_pack_entry* e)
 
 extern "C" int chap_pack_multi(const chap_pack_entry* entries_dev, int32_t n, int64_t max_total, void* stream) {
     CHAP_CHECK_ARG(entries_dev && n > 0 && max_total > 0, "chap_pack_multi: bad argument");
+    CHAP_NOT_IN_GROUP("chap_pack_multi");
     // one fragment unit (8 gathered values) per thread and loop step: the largest layer sets the time (3D 256x256x27: 221k units), so it gets
     // up to 1024 blocks -- 64 made this launch, the first of every iteration, 33 us (2D) / 164 us (3D), now 24 / 103; the small entries'
     // blocks exit at once.  (Tried: one block per (K-chunk, 16-channel tile) reading its runs of the checkpoint tensor coalesced into
@@ -288,6 +288,7 @@ extern "C" size_t chap_pack_size(const chap_pack_params* p) {
 
 extern "C" int chap_pack_weights(const chap_pack_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->w && p->out, "chap_pack_weights: null argument");
+    CHAP_NOT_IN_GROUP("chap_pack_weights");
     pack_geom g;
     int r = pack_geometry(p, &g);
     if (r) return r;

@@ -15,6 +15,7 @@
 // registers across tiles and flushed once per block into that block's partial slot (no atomics).
 #pragma once
 #include "common.h"
+#include "launch.h"
 #include <type_traits>
 
 #ifndef CHAP_CONV_MINWAVES
@@ -363,8 +364,11 @@ __device__ __forceinline__ void tile_coords(long tile, int tiles_x, int tiles_y,
     x0 = (int)tx * TW; y0 = (int)ty * TH;
 }
 
+// __launch_bounds__ second argument of the trampoline (launch.h) that runs this body
+template <int KC, bool D3> constexpr int conv_min_waves() { return CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES : (KC == 16 && !D3 ? 3 : 1); }
+
 template <typename T, int KS, int ST, bool D3, int KC, int NT, int MR, bool ADD2, bool WLDS, bool ZW = false, bool ONE = false>
-__global__ __launch_bounds__(256, (CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES : (KC == 16 && !D3 ? 3 : 1))) void conv_fwd_kernel(const chap_conv_params P) {
+__device__ __forceinline__ void conv_fwd_kernel(const chap_conv_params& P) {
     typedef conv_geom<KS, ST, D3, MR, ZW> G;
     typedef typename frag<T>::type F;
     constexpr int GPT = KC / 8, PS = pix_stride<T, KC>();

@@ -25,7 +25,7 @@ __host__ __device__ constexpr size_t conv_kpar_lds_bytes(int NT) {
 }
 
 template <typename T, bool D3, int KC, int NT, int CPAR, bool ONE>
-__global__ __launch_bounds__(256, 2) void conv_kpar_kernel(const chap_conv_params P) {
+__device__ __forceinline__ void conv_kpar_kernel(const chap_conv_params& P) {      // runs behind chap_grouped<.., 256, 2> (launch.h)
     constexpr int KS = 3, ST = 1, MRG = D3 ? 1 : 2;
     typedef conv_geom<KS, ST, D3, MRG> G;                        // tile = ROWS x 16 pixels of one plane (2D: 8 rows, 3D: 4)
     typedef typename frag<T>::type F;

@@ -5,14 +5,14 @@
 template <bool D3, int KC, int NT, int CPAR, bool ONE>
 static int kpar_launch(const chap_conv_params* p, hipStream_t stream) {
     typedef conv_geom<3, 1, D3, D3 ? 1 : 2> G;
-    auto kern = conv_kpar_kernel<bf16_t, D3, KC, NT, CPAR, ONE>;
+    const void* kern = chap_kernel<chap_conv_params, conv_kpar_kernel<bf16_t, D3, KC, NT, CPAR, ONE>, 256, 2>();
     const size_t lds = conv_kpar_lds_bytes<bf16_t, D3, KC, CPAR>(NT);
     static std::atomic<int> attr_set[16];                       // per device; setting the attribute twice (a race) is harmless
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
     if (!attr_set[dev].load(std::memory_order_acquire)) {
         if (lds > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) { chap_set_error("conv(kpar): hipFuncSetAttribute(%zu) failed: %s", lds, hipGetErrorString(e)); return CHAP_ELAUNCH; }
         }
         attr_set[dev].store(1, std::memory_order_release);
@@ -20,9 +20,7 @@ static int kpar_launch(const chap_conv_params* p, hipStream_t stream) {
     const long ntiles = (long)p->N * p->D * cdiv(p->H, G::TH) * cdiv(p->W, G::TW);
     const long gx = ntiles < CHAP_STATS_MAX_SLOTS ? ntiles : CHAP_STATS_MAX_SLOTS;      // one statistics slot per block (chap_hip.h)
     const int gy = cdiv((p->Cout + 15) / 16, NT);
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, gy), dim3(256), lds, stream, *p);
-    CHAP_LAUNCH_CHECK("chap_conv_fwd(kpar)");
-    return CHAP_OK;
+    return chap_launch_ptr<chap_conv_params>(kern, dim3((unsigned)gx, gy), dim3(256), lds, stream, *p, "chap_conv_fwd(kpar)");
 }
 
 template <bool D3, int KC, int CPAR>

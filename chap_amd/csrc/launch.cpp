@@ -1,0 +1,74 @@
+// Recording / merging of launches between chap_group_begin() and chap_group_end() (launch.h).
+#include <vector>
+#include "launch.h"
+
+namespace {
+struct group_state {
+    bool on = false;
+    hipStream_t stream = nullptr;
+    std::vector<std::vector<chap_pending>> lanes;
+    int error = CHAP_OK;
+};
+thread_local group_state G;
+
+bool same_launch(const chap_pending& a, const chap_pending& b) {
+    return a.fn == b.fn && a.lds == b.lds && a.grid.x == b.grid.x && a.grid.y == b.grid.y && a.grid.z == b.grid.z &&
+           a.block.x == b.block.x && a.block.y == b.block.y && a.block.z == b.block.z;
+}
+}  // namespace
+
+bool chap_group_recording() { return G.on; }
+
+int chap_group_record(const chap_pending& p, hipStream_t s) {
+    if (s != G.stream) {
+        chap_set_error("%s: launched on another stream than the one given to chap_group_begin()", p.name);
+        G.error = CHAP_EINVAL;
+        return CHAP_EINVAL;
+    }
+    G.lanes.back().push_back(p);
+    return CHAP_OK;
+}
+
+extern "C" int chap_group_begin(void* stream) {
+    if (G.on) { chap_set_error("chap_group_begin: already recording (regions do not nest)"); return CHAP_EINVAL; }
+    G.on = true;
+    G.stream = (hipStream_t)stream;
+    G.error = CHAP_OK;
+    G.lanes.clear();
+    G.lanes.emplace_back();
+    return CHAP_OK;
+}
+
+extern "C" int chap_group_next_lane(void) {
+    if (!G.on) { chap_set_error("chap_group_next_lane: not recording"); return CHAP_EINVAL; }
+    G.lanes.emplace_back();
+    return CHAP_OK;
+}
+
+// Issues what was recorded: position j of every lane together when the launches match, at most CHAP_MAX_GROUP per grid;
+// returns the number of grids launched (>= 0) or a negative error code.
+extern "C" int chap_group_end(void) {
+    if (!G.on) { chap_set_error("chap_group_end: not recording"); return CHAP_EINVAL; }
+    G.on = false;
+    int rc = G.error, launched = 0;
+    size_t maxlen = 0;
+    for (const auto& l : G.lanes) maxlen = l.size() > maxlen ? l.size() : maxlen;
+    for (size_t j = 0; j < maxlen && rc == CHAP_OK; ++j) {
+        std::vector<const chap_pending*> items;
+        for (const auto& l : G.lanes) if (j < l.size()) items.push_back(&l[j]);
+        std::vector<char> used(items.size(), 0);
+        for (size_t i = 0; i < items.size() && rc == CHAP_OK; ++i) {
+            if (used[i]) continue;
+            const chap_pending* grp[CHAP_MAX_GROUP];
+            int n = 0;
+            grp[n++] = items[i];
+            used[i] = 1;
+            for (size_t k = i + 1; k < items.size() && n < CHAP_MAX_GROUP; ++k)
+                if (!used[k] && same_launch(*items[i], *items[k])) { grp[n++] = items[k]; used[k] = 1; }
+            rc = items[i]->merged(grp, n, G.stream);
+            ++launched;
+        }
+    }
+    G.lanes.clear();
+    return rc == CHAP_OK ? launched : rc;
+}

@@ -1,0 +1,80 @@
+// Launch layer of libchap_hip.so: every kernel on the networks' forward / backward path is a __device__ body behind ONE generic
+// __global__ trampoline that takes up to CHAP_MAX_GROUP argument blocks and runs block (x, y, z) on block z's arguments.
+//
+// Why: a training iteration is a chain of ~600 dependent launches of kernels that do 2-5 us of work in 8-20 us (fixed cost: launch
+// gap, block prologue, one cold memory round trip).  The two decoders of a DualDecoder run the SAME layer shapes on different
+// tensors, so do two passes of one network (pass A and the first VAT forward): between chap_group_begin() and chap_group_end()
+// the library records the launches per "lane" and then issues the j-th launch of every lane as ONE grid (gridDim.z = lanes) when
+// they resolved to the same kernel instance and launch geometry -- same blocks, same per-block work, same reduction slots, hence
+// bit-identical results to the one-by-one launches, with one fixed cost instead of 2-4.  Lanes that do not match are launched one
+// after the other in lane order.  (include/chap_hip.h: chap_group_begin / chap_group_next_lane / chap_group_end.)
+#pragma once
+#include <cstring>
+#include <type_traits>
+#include "common.h"
+
+constexpr int CHAP_MAX_GROUP = 4;
+template <typename A> struct chap_group { A p[CHAP_MAX_GROUP]; };
+
+// group index of this block: gridDim.z = groups x base_z (base_z = the kernel's own grid.z, 1 for all but the weight gradient)
+__device__ __forceinline__ int chap_group_index(int base_z = 1) { return base_z == 1 ? (int)blockIdx.z : (int)blockIdx.z / base_z; }
+
+template <typename A, void (*BODY)(const A&), int MAXT, int MINW>
+__global__ __launch_bounds__(MAXT, MINW) void chap_grouped(const chap_group<A> G) { BODY(G.p[blockIdx.z]); }
+// kernels whose own grid uses z (the weight gradient): the body finds its group from A::base_z
+template <typename A, void (*BODY)(const A&, int), int MAXT, int MINW>
+__global__ __launch_bounds__(MAXT, MINW) void chap_grouped_z(const chap_group<A> G) {
+    const int bz = G.p[0].base_z;
+    const int grp = (int)blockIdx.z / bz;
+    BODY(G.p[grp], (int)blockIdx.z - grp * bz);
+}
+
+struct chap_pending {
+    const void* fn;
+    dim3 grid, block;
+    unsigned lds;
+    int (*merged)(const chap_pending* const* items, int n, hipStream_t s);
+    const char* name;
+    alignas(16) unsigned char arg[768];
+};
+bool chap_group_recording();
+int chap_group_record(const chap_pending& p, hipStream_t s);
+
+template <typename A>
+static int chap_launch_merged(const chap_pending* const* items, int n, hipStream_t s) {
+    chap_group<A> g;
+    for (int i = 0; i < CHAP_MAX_GROUP; ++i) memcpy(&g.p[i], items[i < n ? i : 0]->arg, sizeof(A));
+    dim3 grid = items[0]->grid;
+    grid.z *= (unsigned)n;
+    void* args[] = {&g};
+    const hipError_t e = hipLaunchKernel(items[0]->fn, grid, items[0]->block, args, items[0]->lds, s);
+    if (e != hipSuccess) { (void)hipGetLastError(); chap_set_error("%s: launch failed: %s", items[0]->name, hipGetErrorString(e)); return CHAP_ELAUNCH; }
+    return CHAP_OK;
+}
+
+template <typename A>
+static int chap_launch_ptr(const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t s, const A& a, const char* name) {
+    static_assert(sizeof(A) <= sizeof(chap_pending::arg) && std::is_trivially_copyable<A>::value, "kernel argument block too large / not POD");
+    chap_pending p;
+    p.fn = fn; p.grid = grid; p.block = block; p.lds = (unsigned)lds; p.merged = &chap_launch_merged<A>; p.name = name;
+    memcpy(p.arg, &a, sizeof(A));
+    if (chap_group_recording()) return chap_group_record(p, s);
+    const chap_pending* one = &p;
+    return chap_launch_merged<A>(&one, 1, s);
+}
+
+template <typename A, void (*BODY)(const A&), int MAXT, int MINW = 1>
+static const void* chap_kernel() { return (const void*)chap_grouped<A, BODY, MAXT, MINW>; }
+
+template <typename A, void (*BODY)(const A&), int MAXT, int MINW = 1>
+static int chap_launch(dim3 grid, dim3 block, size_t lds, hipStream_t s, const A& a, const char* name) {
+    return chap_launch_ptr<A>(chap_kernel<A, BODY, MAXT, MINW>(), grid, block, lds, s, a, name);
+}
+template <typename A, void (*BODY)(const A&, int), int MAXT, int MINW = 1>
+static int chap_launch_z(dim3 grid, dim3 block, size_t lds, hipStream_t s, const A& a, const char* name) {
+    return chap_launch_ptr<A>((const void*)chap_grouped_z<A, BODY, MAXT, MINW>, grid, block, lds, s, a, name);
+}
+
+// entry points whose kernels are launched directly (not through chap_launch) must not be called inside a group region: their
+// launch would overtake the recorded ones
+#define CHAP_NOT_IN_GROUP(name) do { if (chap_group_recording()) { chap_set_error("%s: not allowed between chap_group_begin() and chap_group_end()", name); return CHAP_EUNSUPPORTED; } } while (0)

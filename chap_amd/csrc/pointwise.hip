@@ -4,6 +4,7 @@
 // BN/activation backward pair, layout converters.  All HBM-bound: 16-byte vector accesses along
 // the channel axis, wave64 shuffle reductions, one float atomic per block and channel.
 #include "common.h"
+#include "launch.h"
 
 // Index decoding uses 32-bit unsigned arithmetic (64-bit integer division costs ~100 VALU instructions on
 // gfx950 and turned these streaming kernels VALU-bound); entry points reject tensors with >= 2^32 elements.
@@ -20,7 +21,7 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 // First conv, Cin = 1, k3 s1 "same" (unet.py:50 with in_chns=1; vnet.py:19 with n_channels=1).
 // One thread per output pixel computes all Cout (<= 32) channels; weights + bias live in LDS.
 template <typename T, bool D3, int CO>
-__global__ __launch_bounds__(256) void conv_c1_fwd_kernel(const chap_conv_c1_params P) {
+__device__ __forceinline__ void conv_c1_fwd_kernel(const chap_conv_c1_params& P) {
     constexpr int KD = D3 ? 3 : 1, TAPS = KD * 9;
     __shared__ float ws[CO * TAPS + 2 * CO];
     __shared__ float bstat[4][2 * CO];
@@ -82,19 +83,20 @@ extern "C" int chap_conv_c1_fwd(const chap_conv_c1_params* p, void* stream) {
     dim3 grid((unsigned)(cdiv(npix, 256) < CHAP_STATS_MAX_SLOTS ? cdiv(npix, 256) : CHAP_STATS_MAX_SLOTS));   // one statistics slot per block
     hipStream_t s = (hipStream_t)stream;
     const bool d3 = p->dims == 3, bf = p->dtype == CHAP_BF16;
-    if (bf && d3) hipLaunchKernelGGL((conv_c1_fwd_kernel<bf16_t, true, 16>), grid, dim3(256), 0, s, *p);
-    else if (bf) hipLaunchKernelGGL((conv_c1_fwd_kernel<bf16_t, false, 16>), grid, dim3(256), 0, s, *p);
-    else if (d3) hipLaunchKernelGGL((conv_c1_fwd_kernel<float, true, 16>), grid, dim3(256), 0, s, *p);
-    else hipLaunchKernelGGL((conv_c1_fwd_kernel<float, false, 16>), grid, dim3(256), 0, s, *p);
-    CHAP_LAUNCH_CHECK("chap_conv_c1_fwd");
-    return CHAP_OK;
+    if (bf && d3) return chap_launch<chap_conv_c1_params, conv_c1_fwd_kernel<bf16_t, true, 16>, 256>(grid, dim3(256), 0, s, *p, "chap_conv_c1_fwd");
+    if (bf) return chap_launch<chap_conv_c1_params, conv_c1_fwd_kernel<bf16_t, false, 16>, 256>(grid, dim3(256), 0, s, *p, "chap_conv_c1_fwd");
+    if (d3) return chap_launch<chap_conv_c1_params, conv_c1_fwd_kernel<float, true, 16>, 256>(grid, dim3(256), 0, s, *p, "chap_conv_c1_fwd");
+    return chap_launch<chap_conv_c1_params, conv_c1_fwd_kernel<float, false, 16>, 256>(grid, dim3(256), 0, s, *p, "chap_conv_c1_fwd");
 }
 
 // Backward of the first conv: dx (VAT needs dL/dx), dw, db.
 //   dx[p]      = sum_{tap,c} g[p - tap + pad][c] * w[c][tap]
 //   dw[c][tap] = sum_p x[p + tap - pad] * g[p][c]      (block partials -> ws, then one reduce pass)
+struct c1_bwd_args { chap_conv_c1_bwd_params P; int nblocks; };
 template <typename T, bool D3, int CO>
-__global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const chap_conv_c1_bwd_params P, int nblocks) {
+__device__ __forceinline__ void conv_c1_bwd_kernel(const c1_bwd_args& A) {
+    const chap_conv_c1_bwd_params& P = A.P;
+    const int nblocks = A.nblocks;
     constexpr int KD = D3 ? 3 : 1, TAPS = KD * 9;
     __shared__ float ws[CO * TAPS];
     __shared__ float part[4][CO * TAPS + CO];
@@ -177,8 +179,10 @@ __global__ __launch_bounds__(256) void conv_c1_bwd_kernel(const chap_conv_c1_bwd
     }
 }
 
+struct c1_reduce_args { const float* ws; int nblocks, taps; float* dw; float* db; };
 template <int CO>
-__global__ __launch_bounds__(256) void conv_c1_reduce_kernel(const float* ws, int nblocks, int taps, float* dw, float* db) {
+__device__ __forceinline__ void conv_c1_reduce_kernel(const c1_reduce_args& A) {
+    const float* ws = A.ws; const int nblocks = A.nblocks, taps = A.taps; float* dw = A.dw; float* db = A.db;
     __shared__ float red[4];
     const int i = blockIdx.x;                    // one block per output element, threads stride the block partials
     const int tot = CO * taps + CO;
@@ -209,15 +213,17 @@ extern "C" int chap_conv_c1_bwd(const chap_conv_c1_bwd_params* p, void* stream) 
     const int nb = c1_bwd_blocks(p);
     hipStream_t s = (hipStream_t)stream;
     const bool d3 = p->dims == 3, bf = p->dtype == CHAP_BF16;
-    if (bf && d3) hipLaunchKernelGGL((conv_c1_bwd_kernel<bf16_t, true, 16>), dim3(nb), dim3(256), 0, s, *p, nb);
-    else if (bf) hipLaunchKernelGGL((conv_c1_bwd_kernel<bf16_t, false, 16>), dim3(nb), dim3(256), 0, s, *p, nb);
-    else if (d3) hipLaunchKernelGGL((conv_c1_bwd_kernel<float, true, 16>), dim3(nb), dim3(256), 0, s, *p, nb);
-    else hipLaunchKernelGGL((conv_c1_bwd_kernel<float, false, 16>), dim3(nb), dim3(256), 0, s, *p, nb);
-    CHAP_LAUNCH_CHECK("chap_conv_c1_bwd");
+    const c1_bwd_args a = {*p, nb};
+    int r;
+    if (bf && d3) r = chap_launch<c1_bwd_args, conv_c1_bwd_kernel<bf16_t, true, 16>, 256>(dim3(nb), dim3(256), 0, s, a, "chap_conv_c1_bwd");
+    else if (bf) r = chap_launch<c1_bwd_args, conv_c1_bwd_kernel<bf16_t, false, 16>, 256>(dim3(nb), dim3(256), 0, s, a, "chap_conv_c1_bwd");
+    else if (d3) r = chap_launch<c1_bwd_args, conv_c1_bwd_kernel<float, true, 16>, 256>(dim3(nb), dim3(256), 0, s, a, "chap_conv_c1_bwd");
+    else r = chap_launch<c1_bwd_args, conv_c1_bwd_kernel<float, false, 16>, 256>(dim3(nb), dim3(256), 0, s, a, "chap_conv_c1_bwd");
+    if (r) return r;
     if (p->dw || p->db) {
         const int taps = d3 ? 27 : 9, tot = 16 * taps + 16;
-        hipLaunchKernelGGL((conv_c1_reduce_kernel<16>), dim3(tot), dim3(256), 0, s, (const float*)p->ws, nb, taps, p->dw, p->db);
-        CHAP_LAUNCH_CHECK("chap_conv_c1_bwd(reduce)");
+        const c1_reduce_args ra = {(const float*)p->ws, nb, taps, p->dw, p->db};
+        return chap_launch<c1_reduce_args, conv_c1_reduce_kernel<16>, 256>(dim3(tot), dim3(256), 0, s, ra, "chap_conv_c1_bwd(reduce)");
     }
     return CHAP_OK;
 }
@@ -228,7 +234,7 @@ extern "C" int chap_conv_c1_bwd(const chap_conv_c1_bwd_params* p, void* stream) 
 // One wave per channel: lane l sums slots l, l+64, ... (and the sub-lattice rows of a transposed conv) in fp64, then a
 // fixed xor butterfly -- the same order on every run.  mean = c + S/n, var = Q/n - (S/n)^2 with the moments taken about
 // the conv's shift c (no cancellation once c tracks the mean), evaluated in fp64.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const chap_bn_finalize_params P) {
+__device__ __forceinline__ void bn_finalize_kernel(const chap_bn_finalize_params& P) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= P.C) return;
     const int nslots = *(const int*)P.stats;
@@ -281,12 +287,10 @@ extern "C" int chap_bn_finalize(const chap_bn_finalize_params* p, void* stream) 
     CHAP_CHECK_ARG(p && p->stats && p->gamma && p->beta && p->scale && p->shift && p->C > 0 && p->count > 0, "chap_bn_finalize: bad argument");
     CHAP_CHECK_ARG(p->Clog >= p->C && p->Clog % p->C == 0, "chap_bn_finalize: Clog=%d must be a multiple of C=%d", p->Clog, p->C);
     { static int skip = -1; if (skip < 0) skip = getenv("CHAP_LAB_SKIP_BNFIN") ? 1 : 0; if (skip) return CHAP_OK; }      // lab: timing bound only (wrong numerics)
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(p->C, 4)), dim3(256), 0, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_bn_finalize");
-    return CHAP_OK;
+    return chap_launch<chap_bn_finalize_params, bn_finalize_kernel, 256>(dim3(cdiv(p->C, 4)), dim3(256), 0, (hipStream_t)stream, *p, "chap_bn_finalize");
 }
 
-__global__ void bn_eval_kernel(const chap_bn_eval_params P) {
+__device__ __forceinline__ void bn_eval_kernel(const chap_bn_eval_params& P) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= P.C) return;
     const float sc = P.gamma[c] * rsqrtf(P.running_var[c] + P.eps);
@@ -295,15 +299,13 @@ __global__ void bn_eval_kernel(const chap_bn_eval_params P) {
 }
 extern "C" int chap_bn_eval_affine(const chap_bn_eval_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->gamma && p->beta && p->running_mean && p->running_var && p->scale && p->shift && p->C > 0, "chap_bn_eval_affine: bad argument");
-    hipLaunchKernelGGL(bn_eval_kernel, dim3(cdiv(p->C, 64)), dim3(64), 0, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_bn_eval_affine");
-    return CHAP_OK;
+    return chap_launch<chap_bn_eval_params, bn_eval_kernel, 64>(dim3(cdiv(p->C, 64)), dim3(64), 0, (hipStream_t)stream, *p, "chap_bn_eval_affine");
 }
 
 // =========================================================================================
 // 2x2 max-pool of a lazy activation. One thread per (pooled pixel, 8 channels).
 template <typename T>
-__global__ __launch_bounds__(256) void act_pool2_kernel(const chap_pool_params P) {
+__device__ __forceinline__ void act_pool2_kernel(const chap_pool_params& P) {
     const int D = P.D > 1 ? P.D : 1, KZ = P.D > 1 ? 2 : 1;
     const int C8 = P.r.C / 8, OD = D / KZ, OH = P.H / 2, OW = P.W / 2;
     const long total = (long)P.N * OD * OH * OW * C8;
@@ -337,10 +339,8 @@ extern "C" int chap_act_pool2(const chap_pool_params* p, void* stream) {
     CHAP_CHECK_ARG(p->r.C % 8 == 0 && p->H % 2 == 0 && p->W % 2 == 0 && (p->D <= 1 || p->D % 2 == 0), "chap_act_pool2: C%%8, even dims required");
     const long total = (long)p->N * (p->D > 1 ? p->D / 2 : 1) * (p->H / 2) * (p->W / 2) * (p->r.C / 8);
     const int blocks = chap_blocks(total, 4096);
-    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(act_pool2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL(act_pool2_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_act_pool2");
-    return CHAP_OK;
+    if (p->dtype == CHAP_BF16) return chap_launch<chap_pool_params, act_pool2_kernel<bf16_t>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_act_pool2");
+    return chap_launch<chap_pool_params, act_pool2_kernel<float>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_act_pool2");
 }
 
 // =========================================================================================
@@ -356,7 +356,7 @@ __device__ __forceinline__ void ac_coord(int o, int in, int out, int& i0, int& i
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void upsample2x_kernel(const chap_upsample_params P) {
+__device__ __forceinline__ void upsample2x_kernel(const chap_upsample_params& P) {
     const int C8 = P.r.C / 8;
     const int OD = P.dims == 3 ? 2 * P.D : P.D, OH = 2 * P.H, OW = 2 * P.W;
     const long total = (long)P.N * OD * OH * OW * C8;
@@ -405,7 +405,7 @@ __device__ __forceinline__ int up_axis_outputs(int i, int in, int out, bool hp, 
     return n;
 }
 template <typename T, bool D3>
-__global__ __launch_bounds__(256) void upsample2x_cell_kernel(const chap_upsample_params P) {
+__device__ __forceinline__ void upsample2x_cell_kernel(const chap_upsample_params& P) {
     const int C8 = P.r.C / 8;
     const int OD = D3 ? 2 * P.D : P.D, OH = 2 * P.H, OW = 2 * P.W;
     const int CD = D3 ? P.D - 1 : P.D, CH = P.H - 1, CW = P.W - 1;       // cells per axis
@@ -460,17 +460,15 @@ extern "C" int chap_upsample2x(const chap_upsample_params* p, void* stream) {
         const long cells = (long)p->N * (d3 ? p->D - 1 : p->D) * (p->H - 1) * (p->W - 1) * (p->r.C / 8);
         const int blocks = chap_blocks(cells, 16384);
         hipStream_t s = (hipStream_t)stream;
-        if (p->dtype == CHAP_BF16) { if (d3) hipLaunchKernelGGL((upsample2x_cell_kernel<bf16_t, true>), dim3(blocks), dim3(256), 0, s, *p); else hipLaunchKernelGGL((upsample2x_cell_kernel<bf16_t, false>), dim3(blocks), dim3(256), 0, s, *p); }
-        else { if (d3) hipLaunchKernelGGL((upsample2x_cell_kernel<float, true>), dim3(blocks), dim3(256), 0, s, *p); else hipLaunchKernelGGL((upsample2x_cell_kernel<float, false>), dim3(blocks), dim3(256), 0, s, *p); }
-        CHAP_LAUNCH_CHECK("chap_upsample2x");
-        return CHAP_OK;
+        if (p->dtype == CHAP_BF16) return d3 ? chap_launch<chap_upsample_params, upsample2x_cell_kernel<bf16_t, true>, 256>(dim3(blocks), dim3(256), 0, s, *p, "chap_upsample2x")
+                                             : chap_launch<chap_upsample_params, upsample2x_cell_kernel<bf16_t, false>, 256>(dim3(blocks), dim3(256), 0, s, *p, "chap_upsample2x");
+        return d3 ? chap_launch<chap_upsample_params, upsample2x_cell_kernel<float, true>, 256>(dim3(blocks), dim3(256), 0, s, *p, "chap_upsample2x")
+                  : chap_launch<chap_upsample_params, upsample2x_cell_kernel<float, false>, 256>(dim3(blocks), dim3(256), 0, s, *p, "chap_upsample2x");
     }
     const long total = (long)p->N * (p->dims == 3 ? 2 * p->D : p->D) * 2 * p->H * 2 * p->W * (p->r.C / 8);
     const int blocks = chap_blocks(total, 8192);
-    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(upsample2x_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL(upsample2x_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_upsample2x");
-    return CHAP_OK;
+    if (p->dtype == CHAP_BF16) return chap_launch<chap_upsample_params, upsample2x_kernel<bf16_t>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_upsample2x");
+    return chap_launch<chap_upsample_params, upsample2x_kernel<float>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_upsample2x");
 }
 
 // Adjoint: each coarse pixel gathers from the fine pixels whose stencil touches it (no atomics).
@@ -488,7 +486,7 @@ __device__ __forceinline__ int up_axis_adjoint(int i, int in, int out, int o_[5]
     return n;
 }
 template <typename T>
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const chap_upsample_bwd_params P) {
+__device__ __forceinline__ void upsample2x_bwd_kernel(const chap_upsample_bwd_params& P) {
     const int C8 = P.C / 8;
     const int OD = P.dims == 3 ? 2 * P.D : P.D, OH = 2 * P.H, OW = 2 * P.W;
     const long total = (long)P.N * P.D * P.H * P.W * C8;
@@ -526,10 +524,8 @@ extern "C" int chap_upsample2x_bwd(const chap_upsample_bwd_params* p, void* stre
     CHAP_CHECK_ARG(p && p->g && p->out && p->C % 8 == 0 && p->g_ld % 8 == 0 && p->g_coff % 8 == 0, "chap_upsample2x_bwd: bad argument");
     const long total = (long)p->N * p->D * p->H * p->W * (p->C / 8);
     const int blocks = chap_blocks(total, 8192);
-    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(upsample2x_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL(upsample2x_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_upsample2x_bwd");
-    return CHAP_OK;
+    if (p->dtype == CHAP_BF16) return chap_launch<chap_upsample_bwd_params, upsample2x_bwd_kernel<bf16_t>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_upsample2x_bwd");
+    return chap_launch<chap_upsample_bwd_params, upsample2x_bwd_kernel<float>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_upsample2x_bwd");
 }
 
 // =========================================================================================
@@ -599,7 +595,7 @@ __device__ __forceinline__ void act_bwd_dz(const chap_act_bwd_params& P, const f
 }
 
 template <typename T, bool APPLY>
-__global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params P) {
+__device__ __forceinline__ void act_bwd_kernel(const chap_act_bwd_params& P) {
     extern __shared__ float red[];            // reduce phase: [4 waves][2][C] partials; apply phase: [2][C] totals
     const int C = P.r.C, C8 = C / 8;
     const long npix = (long)P.N * P.D * P.H * P.W;
@@ -697,7 +693,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const chap_act_bwd_params 
 
 // Fixed-order total of the per-block partial rows (one wave per value, fp64) into row 0, read by the apply phase;
 // accumulates the BatchNorm parameter gradients.
-__global__ __launch_bounds__(256) void act_bwd_sum_kernel(float* sums, int nblocks, float* dgamma, float* dbeta, int C) {
+struct act_bwd_sum_args { float* sums; int nblocks; float* dgamma; float* dbeta; int C; };
+__device__ __forceinline__ void act_bwd_sum_kernel(const act_bwd_sum_args& A) {
+    float* sums = A.sums; const int nblocks = A.nblocks; float* dgamma = A.dgamma; float* dbeta = A.dbeta; const int C = A.C;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= 2 * C) return;
     double t = 0.0;
@@ -742,28 +740,25 @@ extern "C" int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream) {
     CHAP_CHECK_ARG(p->bn && p->mean && p->invstd && p->sums, "chap_act_bwd_reduce: needs bn, mean, invstd, sums");
     const size_t lds = 4 * 2 * p->r.C * sizeof(float);
     const int nb = act_bwd_blocks(p);
-    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, false>), dim3(nb), dim3(256), lds, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL((act_bwd_kernel<float, false>), dim3(nb), dim3(256), lds, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_act_bwd_reduce");
+    if (p->dtype == CHAP_BF16) r = chap_launch<chap_act_bwd_params, act_bwd_kernel<bf16_t, false>, 256>(dim3(nb), dim3(256), lds, (hipStream_t)stream, *p, "chap_act_bwd_reduce");
+    else r = chap_launch<chap_act_bwd_params, act_bwd_kernel<float, false>, 256>(dim3(nb), dim3(256), lds, (hipStream_t)stream, *p, "chap_act_bwd_reduce");
+    if (r) return r;
     { static int skip = -1; if (skip < 0) skip = getenv("CHAP_LAB_SKIP_ACTSUM") ? 1 : 0; if (skip) return CHAP_OK; }     // lab: timing bound only (wrong numerics)
-    hipLaunchKernelGGL(act_bwd_sum_kernel, dim3(cdiv(2 * p->r.C, 4)), dim3(256), 0, (hipStream_t)stream, p->sums, nb, p->dgamma, p->dbeta, p->r.C);
-    CHAP_LAUNCH_CHECK("chap_act_bwd_reduce(sum)");
-    return CHAP_OK;
+    const act_bwd_sum_args sa = {p->sums, nb, p->dgamma, p->dbeta, p->r.C};
+    return chap_launch<act_bwd_sum_args, act_bwd_sum_kernel, 256>(dim3(cdiv(2 * p->r.C, 4)), dim3(256), 0, (hipStream_t)stream, sa, "chap_act_bwd_reduce(sum)");
 }
 extern "C" int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream) {
     int r = act_bwd_check(p); if (r) return r;
     CHAP_CHECK_ARG(p->gout, "chap_act_bwd_apply: null gout");
     const size_t lds = 2 * p->r.C * sizeof(float);
-    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL((act_bwd_kernel<bf16_t, true>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL((act_bwd_kernel<float, true>), dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_act_bwd_apply");
-    return CHAP_OK;
+    if (p->dtype == CHAP_BF16) return chap_launch<chap_act_bwd_params, act_bwd_kernel<bf16_t, true>, 256>(dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p, "chap_act_bwd_apply");
+    return chap_launch<chap_act_bwd_params, act_bwd_kernel<float, true>, 256>(dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p, "chap_act_bwd_apply");
 }
 
 // =========================================================================================
 // Layout converters at the module boundary.
 template <typename T>
-__global__ void planar_to_cl_kernel(const chap_planar_to_cl_params P) {
+__device__ __forceinline__ void planar_to_cl_kernel(const chap_planar_to_cl_params& P) {
     const int Cp = P.Cpad > P.C ? P.Cpad : P.C;       // channels [C, Cpad) are written as zeros
     const long total = (long)P.N * P.P * Cp;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -776,7 +771,7 @@ __global__ void planar_to_cl_kernel(const chap_planar_to_cl_params P) {
 }
 // vector form: thread = (pixel, 8 channels), one 16-/32-byte store (the scalar form above writes 2 bytes per thread)
 template <typename T>
-__global__ __launch_bounds__(256) void planar_to_cl8_kernel(const chap_planar_to_cl_params P) {
+__device__ __forceinline__ void planar_to_cl8_kernel(const chap_planar_to_cl_params& P) {
     const int Cp = P.Cpad > P.C ? P.Cpad : P.C, C8 = Cp / 8;
     const long total = (long)P.N * P.P * C8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -795,21 +790,17 @@ extern "C" int chap_planar_to_cl(const chap_planar_to_cl_params* p, void* stream
     if (Cp % 8 == 0 && p->out_ld % 8 == 0 && p->out_coff % 8 == 0) {
         const long total = (long)p->N * p->P * (Cp / 8);
         const int blocks = chap_blocks(total, 16384);
-        if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(planar_to_cl8_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-        else hipLaunchKernelGGL(planar_to_cl8_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-        CHAP_LAUNCH_CHECK("chap_planar_to_cl");
-        return CHAP_OK;
+        if (p->dtype == CHAP_BF16) return chap_launch<chap_planar_to_cl_params, planar_to_cl8_kernel<bf16_t>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_planar_to_cl");
+        return chap_launch<chap_planar_to_cl_params, planar_to_cl8_kernel<float>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_planar_to_cl");
     }
     const long total = (long)p->N * p->P * Cp;
     const int blocks = chap_blocks(total, 4096);
-    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(planar_to_cl_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL(planar_to_cl_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_planar_to_cl");
-    return CHAP_OK;
+    if (p->dtype == CHAP_BF16) return chap_launch<chap_planar_to_cl_params, planar_to_cl_kernel<bf16_t>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_planar_to_cl");
+    return chap_launch<chap_planar_to_cl_params, planar_to_cl_kernel<float>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_planar_to_cl");
 }
 
 template <typename T>
-__global__ void cl_to_planar_kernel(const chap_cl_to_planar_params P) {
+__device__ __forceinline__ void cl_to_planar_kernel(const chap_cl_to_planar_params& P) {
     const int C = P.r.C;
     const long total = (long)P.N * P.P * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -823,17 +814,15 @@ extern "C" int chap_cl_to_planar(const chap_cl_to_planar_params* p, void* stream
     CHAP_CHECK_ARG(p && p->r.ptr && p->out, "chap_cl_to_planar: null argument");
     const long total = (long)p->N * p->P * p->r.C;
     const int blocks = chap_blocks(total, 4096);
-    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(cl_to_planar_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL(cl_to_planar_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_cl_to_planar");
-    return CHAP_OK;
+    if (p->dtype == CHAP_BF16) return chap_launch<chap_cl_to_planar_params, cl_to_planar_kernel<bf16_t>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_cl_to_planar");
+    return chap_launch<chap_cl_to_planar_params, cl_to_planar_kernel<float>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_cl_to_planar");
 }
 
 // =========================================================================================
 // out[c] += sum over pixels of a (lazy) channel-last tensor: bias gradient of layers whose output
 // gradient is not the B operand of chap_wgrad (transposed conv).
 template <typename T>
-__global__ __launch_bounds__(256) void channel_sum_kernel(const chap_chansum_params P) {
+__device__ __forceinline__ void channel_sum_kernel(const chap_chansum_params& P) {
     extern __shared__ float red[];             // [4 waves][C]
     const int C = P.r.C, C8 = C / 8;
     const int c8 = (threadIdx.x % C8) * 8, prow = threadIdx.x / C8, PPB = 256 / C8;
@@ -859,7 +848,9 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const chap_chansum_par
     for (int i = threadIdx.x; i < C; i += 256) P.ws[(long)blockIdx.x * C + i] = (red[i] + red[C + i]) + (red[2 * C + i] + red[3 * C + i]);
 }
 // out[c] += fixed-order total of the block partials (one wave per channel, fp64)
-__global__ __launch_bounds__(256) void channel_sum_final_kernel(const float* ws, int nblocks, int C, float* out) {
+struct chansum_final_args { const float* ws; int nblocks, C; float* out; };
+__device__ __forceinline__ void channel_sum_final_kernel(const chansum_final_args& A) {
+    const float* ws = A.ws; const int nblocks = A.nblocks, C = A.C; float* out = A.out;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double t = 0.0;
@@ -873,10 +864,10 @@ extern "C" int chap_channel_sum(const chap_chansum_params* p, void* stream) {
     long b = (p->npix + ppb - 1) / ppb;
     const int nb = (int)(b < CHAP_CHANSUM_SLOTS ? b : CHAP_CHANSUM_SLOTS);
     const size_t lds = 4 * p->r.C * sizeof(float);
-    if (p->dtype == CHAP_BF16) hipLaunchKernelGGL(channel_sum_kernel<bf16_t>, dim3(nb), dim3(256), lds, (hipStream_t)stream, *p);
-    else hipLaunchKernelGGL(channel_sum_kernel<float>, dim3(nb), dim3(256), lds, (hipStream_t)stream, *p);
-    CHAP_LAUNCH_CHECK("chap_channel_sum");
-    hipLaunchKernelGGL(channel_sum_final_kernel, dim3(cdiv(p->r.C, 4)), dim3(256), 0, (hipStream_t)stream, (const float*)p->ws, nb, p->r.C, p->out);
-    CHAP_LAUNCH_CHECK("chap_channel_sum(final)");
-    return CHAP_OK;
+    int r;
+    if (p->dtype == CHAP_BF16) r = chap_launch<chap_chansum_params, channel_sum_kernel<bf16_t>, 256>(dim3(nb), dim3(256), lds, (hipStream_t)stream, *p, "chap_channel_sum");
+    else r = chap_launch<chap_chansum_params, channel_sum_kernel<float>, 256>(dim3(nb), dim3(256), lds, (hipStream_t)stream, *p, "chap_channel_sum");
+    if (r) return r;
+    const chansum_final_args fa = {(const float*)p->ws, nb, p->r.C, p->out};
+    return chap_launch<chansum_final_args, channel_sum_final_kernel, 256>(dim3(cdiv(p->r.C, 4)), dim3(256), 0, (hipStream_t)stream, fa, "chap_channel_sum(final)");
 }

@@ -2,6 +2,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include "common.h"
+#include "launch.h"
 
 int chap_wgrad_launch_bf16(const chap_wgrad_params* p, int KC, int brick, float* ws, float* ws_db, int nsplit, int Ca, int Cb, hipStream_t s);
 int chap_wgrad_launch_f32(const chap_wgrad_params* p, int KC, int brick, float* ws, float* ws_db, int nsplit, int Ca, int Cb, hipStream_t s);
@@ -85,9 +86,13 @@ extern "C" size_t chap_wgrad_ws(const chap_wgrad_params* p) {
 // few-slab / large-weight layers, E4 = 8 (G = 32) when there are many slabs of a small weight.
 // Fixed summation order -> bitwise reproducible.  total % 4 == 0 (Cb is a multiple of 16).
 // Blocks [0, nb_dw) reduce dW, blocks [nb_dw, ...) reduce the bias-gradient partials the same way.
+struct wgrad_reduce_args { const float* ws; const float* ws_db; int nsplit, taps, Ca, Cb; float* dw; long s_tap, s_kc, s_kn; int kc_valid, kn_valid; float* db; int nb_dw; };
 template <int E4>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, const float* __restrict__ ws_db, int nsplit, int taps, int Ca, int Cb,
-                                                           float* dw, long s_tap, long s_kc, long s_kn, int kc_valid, int kn_valid, float* db, int nb_dw) {
+__device__ __forceinline__ void wgrad_reduce_kernel(const wgrad_reduce_args& A) {
+    const float* __restrict__ ws = A.ws; const float* __restrict__ ws_db = A.ws_db;
+    const int nsplit = A.nsplit, taps = A.taps, Ca = A.Ca, Cb = A.Cb, kc_valid = A.kc_valid, kn_valid = A.kn_valid, nb_dw = A.nb_dw;
+    float* dw = A.dw; float* db = A.db;
+    const long s_tap = A.s_tap, s_kc = A.s_kc, s_kn = A.s_kn;
     constexpr int G = 256 / E4;
     __shared__ float4 red[G][E4];
     const int col = threadIdx.x % E4, g = threadIdx.x / E4;
@@ -144,17 +149,13 @@ extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     if (r) return r;
     const long total = (long)q.taps * q.Ca * q.Cb;
     const int kcv = p->kc_valid > 0 ? p->kc_valid : q.Ca, knv = p->kn_valid > 0 ? p->kn_valid : q.Cb;
+    wgrad_reduce_args ra = {(const float*)ws, (const float*)ws_db, q.nsplit, q.taps, q.Ca, q.Cb, p->dw, (long)p->s_tap, (long)p->s_kc, (long)p->s_kn, kcv, knv, p->db, 0};
     if (q.nsplit >= 64) {      // (8 elements per block / 128 slab groups for the 768-split layers measured 25 us against 7 us: too few loads in flight per thread)
         const int nb_db = p->db ? cdiv(q.Cb, 32) : 0;
-        const int nb_dw = cdiv(total, 32);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(nb_dw + nb_db), dim3(256), 0, s, (const float*)ws, (const float*)ws_db, q.nsplit, q.taps, q.Ca, q.Cb,
-                           p->dw, (long)p->s_tap, (long)p->s_kc, (long)p->s_kn, kcv, knv, p->db, nb_dw);
-    } else {
-        const int nb_db = p->db ? cdiv(q.Cb, 256) : 0;
-        const int nb_dw = cdiv(total, 256);
-        hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(nb_dw + nb_db), dim3(256), 0, s, (const float*)ws, (const float*)ws_db, q.nsplit, q.taps, q.Ca, q.Cb,
-                           p->dw, (long)p->s_tap, (long)p->s_kc, (long)p->s_kn, kcv, knv, p->db, nb_dw);
+        ra.nb_dw = cdiv(total, 32);
+        return chap_launch<wgrad_reduce_args, wgrad_reduce_kernel<8>, 256>(dim3(ra.nb_dw + nb_db), dim3(256), 0, s, ra, "chap_wgrad(reduce)");
     }
-    CHAP_LAUNCH_CHECK("chap_wgrad(reduce)");
-    return CHAP_OK;
+    const int nb_db = p->db ? cdiv(q.Cb, 256) : 0;
+    ra.nb_dw = cdiv(total, 256);
+    return chap_launch<wgrad_reduce_args, wgrad_reduce_kernel<64>, 256>(dim3(ra.nb_dw + nb_db), dim3(256), 0, s, ra, "chap_wgrad(reduce)");
 }

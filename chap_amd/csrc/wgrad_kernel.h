@@ -47,9 +47,15 @@ __device__ __forceinline__ s16x4 lds_tr16(const bf16_t* p) {
 // (tap, 16-row) pairs as always, the brick only changes which pixels a tile holds): its halo is 6 x 6 x 18 = 2.5 A-pixels per
 // output pixel where the 1 x 4 x 16 slab stages 3 x 6 x 18 = 5.1, and one barrier / prefetch round trip serves 256 pixels
 // instead of 64.
+// argument block of one launch (launch.h): base_z = the kernel's own grid.z (B-channel chunks); a grouped launch stacks groups along z
+struct wgrad_args { chap_wgrad_params P; float* ws; float* ws_db; int nsplit, Ca, Cb, base_z; };
+
 template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int BN = WG_BN, int PD = 1, bool ZW = false>
-__global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, float* __restrict__ ws, float* __restrict__ ws_db,
-                                                    int nsplit, int Ca, int Cb) {
+__device__ __forceinline__ void wgrad_kernel(const wgrad_args& A, int nb) {      // runs behind chap_grouped_z<.., 256, 1>
+    const chap_wgrad_params& P = A.P;
+    float* __restrict__ ws = A.ws;
+    float* __restrict__ ws_db = A.ws_db;
+    const int nsplit = A.nsplit, Ca = A.Ca, Cb = A.Cb;
     typedef conv_geom<KS, ST, D3, MR, ZW> G;
     constexpr int TPX = G::TD * G::TH * G::TW;           // pixels per tile
     static_assert(!ZW || (sizeof(T) == 2 && D3 && TPX % 32 == 0 && G::TH % 2 == 0), "brick tiles: 3D bf16 only");
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const chap_wgrad_params P, f
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int split = blockIdx.x, chunk = blockIdx.y, nb = blockIdx.z;
+    const int split = blockIdx.x, chunk = blockIdx.y;
     const int tiles_x = (P.W + G::TW - 1) / G::TW, tiles_y = (P.H + G::TH - 1) / G::TH, tiles_z = (P.D + G::TD - 1) / G::TD;
     const long ntiles = (long)P.N * tiles_z * tiles_y * tiles_x;
     const long my_tiles = split < ntiles ? (ntiles - split + nsplit - 1) / nsplit : 0;

@@ -57,6 +57,42 @@ def _taps(op, dims):
     return op.ksize ** dims
 
 
+def _op_sig(op):
+    """What two ops must share to resolve to the same kernel launches (same instance, grid, call sequence)."""
+    return (op.kind, op.ksize, op.cin, op.cout, bool(op.bn), op.head, op.combine, op.inorm, op.half_pixel, len(op.srcs),
+            None if not op.drop else (op.drop[1], op.drop[2]), op.slope)
+
+
+def zip_branches(a_ops, b_ops):
+    """Align the op lists of two decoders (program order): [(op_a, op_b)] for same-shaped ops -- they become the two lanes of
+    one grouped launch region -- and [(op,)] for the ones without a partner (decoder 1: 1x1 conv + up-sampling, decoder 2:
+    transposed conv).  Each list keeps its order, so every op still runs after the ops of its own branch it depends on."""
+    out, i, j = [], 0, 0
+    while i < len(a_ops) or j < len(b_ops):
+        if i < len(a_ops) and j < len(b_ops) and _op_sig(a_ops[i]) == _op_sig(b_ops[j]):
+            out.append((a_ops[i], b_ops[j]))
+            i, j = i + 1, j + 1
+            continue
+        best = None
+        for di in range(0, min(4, len(a_ops) - i) + 1):
+            for dj in range(0, min(4, len(b_ops) - j) + 1):
+                if (di or dj) and i + di < len(a_ops) and j + dj < len(b_ops) and _op_sig(a_ops[i + di]) == _op_sig(b_ops[j + dj]):
+                    if best is None or di + dj < best[0] + best[1]:
+                        best = (di, dj)
+        if best is None:
+            best = (len(a_ops) - i, len(b_ops) - j)
+        out += [(o,) for o in a_ops[i:i + best[0]]] + [(o,) for o in b_ops[j:j + best[1]]]
+        i, j = i + best[0], j + best[1]
+    return out
+
+
+def grouping_mode():
+    """CHAP_GROUP (lab / A-B switch): 0 = never group (round 2: decoders back to back where a pass cannot fork), 1 (default) = group the
+    two decoders' same-shaped layers in the passes that cannot fork a second stream, 2 = group in every pass (no second stream)."""
+    import os
+    return int(os.environ.get("CHAP_GROUP", "1"))
+
+
 class Saved:
     """What one forward pass leaves behind for its backward pass."""
 
@@ -105,6 +141,15 @@ class Executor:
             self._sides[key] = st
         return st
 
+    def _zipped(self):
+        """The aligned schedule of the two decoder branches (zip_branches), built once per program."""
+        z = getattr(self, "_zip", None)
+        if z is None:
+            b1 = [op for op in self.prog.ops if op.branch == 1]
+            b2 = [op for op in self.prog.ops if op.branch == 2]
+            z = self._zip = zip_branches(b1, b2)
+        return z
+
     def _pack_kinds(self, op):
         if op.kind == "conv":
             return (L.PACK_CONV_FWD, L.PACK_CONV_DGRAD)
@@ -130,7 +175,7 @@ class Executor:
                 p = L.PackParams()
                 p.w, p.kind, p.Cin, p.Cout, p.taps = w.data_ptr(), kind, cin, cout, _taps(op, self.prog.dims)
                 p.dtype = L.F32 if dtype == torch.float32 else L.BF16
-                buf = torch.empty(L.size_of("chap_pack_size", p), dtype=torch.uint8, device=dev)
+                buf = L.hold_empty(L.size_of("chap_pack_size", p), dtype=torch.uint8, device=dev)
                 p.out = buf.data_ptr()
                 e = L.pack_describe(p)
                 entries.append(e)
@@ -175,7 +220,7 @@ class Executor:
             return op.cout * (2 ** dims) if op.kind == "deconv" else op.cout
         nbn = sum(op.cout for op in prog.ops if op.bn or op.inorm)
         nstat = sum(ops.stats_size(clog(op)) for op in prog.ops if (op.bn and train) or op.inorm)
-        arena = torch.empty(nstat + nbn * 4, dtype=torch.float32, device=dev)
+        arena = L.hold_empty(nstat + nbn * 4, dtype=torch.float32, device=dev)
         apos = 0
         # shift of the statistics' moments (sum(x - c), sum((x - c)^2)): a pass-private snapshot of the running means, so
         # that the conv and its finalize see the same c whatever another stream's pass does to the running statistics
@@ -186,7 +231,7 @@ class Executor:
             if shift_snap is None:
                 # sized by the module's running-mean buffer, not by the program's BN channel count (a module may own BatchNorm
                 # layers that this program never runs)
-                shift_snap = torch.empty_like(rm_flat)
+                shift_snap = L.hold_empty_like(rm_flat)
                 shift_snap.copy_(rm_flat)
 
         def take(n):
@@ -198,7 +243,10 @@ class Executor:
         outs = {}
         cur_stream = torch.cuda.current_stream()
         branches = sorted({op.branch for op in prog.ops})
-        side = self._side_stream(cur_stream) if len(branches) > 2 else None
+        # two decoders: on a second stream where this pass may fork one (eager; under capture only from the capture's origin
+        # stream), otherwise in lockstep with grouped launches.  CHAP_GROUP=2 (lab): lockstep everywhere.
+        side = self._side_stream(cur_stream) if (len(branches) > 2 and grouping_mode() != 2) else None
+        zipped = self._zipped() if (side is None and len(branches) == 3 and grouping_mode() != 0) else None
 
         # Dropout seeds are drawn HERE, in program order: the order in which the ops are ISSUED depends on whether this pass
         # may fork its second decoder (eager / captured, which stream), and a seed must not (round 2: the early VAT pass drew
@@ -215,8 +263,8 @@ class Executor:
                 src = V[op.srcs[0]]
                 d, h, w = vdims[op.srcs[0]]
                 od = d // 2 if dims == 3 else 1
-                out = torch.empty(n, od, h // 2, w // 2, src.C, dtype=dtype, device=dev)
-                idx = torch.empty(n, od, h // 2, w // 2, src.C, dtype=torch.uint8, device=dev) if save else None
+                out = L.hold_empty(n, od, h // 2, w // 2, src.C, dtype=dtype, device=dev)
+                idx = L.hold_empty(n, od, h // 2, w // 2, src.C, dtype=torch.uint8, device=dev) if save else None
                 ops.act_pool2(src, out, idx, dims=dims)
                 V[op.out], vdims[op.out] = Lazy(out), (od, h // 2, w // 2)
                 if save:
@@ -226,7 +274,7 @@ class Executor:
                 src = V[op.srcs[0]]
                 d, h, w = vdims[op.srcs[0]]
                 od = 2 * d if dims == 3 else d
-                out = torch.empty(n, od, 2 * h, 2 * w, src.C, dtype=dtype, device=dev)
+                out = L.hold_empty(n, od, 2 * h, 2 * w, src.C, dtype=dtype, device=dev)
                 ops.upsample2x(src, out, dims=dims, half_pixel=op.half_pixel)
                 V[op.out], vdims[op.out] = Lazy(out), (od, 2 * h, 2 * w)
                 return
@@ -239,9 +287,9 @@ class Executor:
             bias = sd[op.b] if op.b else None
             if k == "c1":
                 gd = (D, H, W)
-                out = torch.empty(n, D, H, W, op.cout, dtype=dtype, device=dev)
+                out = L.hold_empty(n, D, H, W, op.cout, dtype=dtype, device=dev)
                 if dtype == torch.bfloat16:
-                    xpad = torch.empty(n, D, H, W, 16, dtype=dtype, device=dev)
+                    xpad = L.hold_empty(n, D, H, W, 16, dtype=dtype, device=dev)
                     ops.planar_to_cl(x, xpad, cpad=16)
                     S.xpad = xpad
                     wp = self._pack(op, L.PACK_CONV_FWD, dtype, sd)
@@ -261,7 +309,7 @@ class Executor:
                     gd, ind, ks, st, kind = (sd_, sh_, sw_), (sd_, sh_, sw_), 1, 1, L.PACK_DECONV_FWD
                 wp = self._pack(op, kind, dtype, sd)
                 if op.head:
-                    out = torch.empty((n, op.cout) + ((gd[1], gd[2]) if dims == 2 else gd), dtype=torch.float32, device=dev)
+                    out = L.hold_empty((n, op.cout) + ((gd[1], gd[2]) if dims == 2 else gd), dtype=torch.float32, device=dev)
                     ops.conv_fwd(srcs, wp, bias, op.cout, out, grid=(n,) + gd, in_dims=ind, ksize=ks, stride=st, dims=dims,
                                  combine=op.combine, out_planar=True, out_f32=True)
                     outs[op.out] = out
@@ -269,12 +317,12 @@ class Executor:
                     return
                 if k == "deconv":
                     od = (2 * gd[0] if dims == 3 else gd[0], 2 * gd[1], 2 * gd[2])
-                    out = torch.empty((n,) + od + (op.cout,), dtype=dtype, device=dev)
+                    out = L.hold_empty((n,) + od + (op.cout,), dtype=dtype, device=dev)
                     ops.conv_fwd(srcs, wp, bias, (2 ** dims) * op.cout, out, grid=(n,) + gd, in_dims=ind, ksize=1, stride=1, dims=dims,
                                  combine=op.combine, out_mode=1, out_cn=op.cout, stats=stats, stats_shift=sshift)
                     gd = od
                 else:
-                    out = torch.empty((n,) + gd + (op.cout,), dtype=dtype, device=dev)
+                    out = L.hold_empty((n,) + gd + (op.cout,), dtype=dtype, device=dev)
                     ops.conv_fwd(srcs, wp, bias, op.cout, out, grid=(n,) + gd, in_dims=ind, ksize=ks, stride=st, dims=dims,
                                  combine=op.combine, stats=stats, stats_shift=sshift)
             vdims[op.out] = gd
@@ -309,7 +357,7 @@ class Executor:
                     if drop_masks is not None:
                         keep = drop_masks.get(site)
                     else:
-                        keep = torch.empty(out.shape, dtype=torch.uint8, device=dev)
+                        keep = L.hold_empty(out.shape, dtype=torch.uint8, device=dev)
                         ops.keep_mask(keep, drop_seed[id(op)], p, seed_dev=rng.seed_dev)
                     if keep is not None:
                         lz.keep, lz.keep_scale = keep, 1.0 / (1.0 - p)
@@ -317,7 +365,7 @@ class Executor:
                     if drop_masks is not None:
                         cm = drop_masks.get(site)
                     else:
-                        cm = torch.empty(n, op.cout, dtype=torch.float32, device=dev)
+                        cm = L.hold_empty(n, op.cout, dtype=torch.float32, device=dev)
                         ops.chan_mask(cm, drop_seed[id(op)], p, seed_dev=rng.seed_dev)
                     if cm is not None:
                         lz.chan_mul = cm
@@ -337,7 +385,20 @@ class Executor:
             run_dec = lambda op: run_op(op, tables[op.branch], n_dec)      # noqa: E731
         else:
             run_dec = run_op
-        if side is not None:
+        if zipped is not None:
+            # the two decoders in lockstep: same-shaped layers (ConvBlock convs, their BatchNorm finalizes, the heads) are the two lanes
+            # of ONE grouped launch (chap_hip.h, chap_group_*): half the launches of the decoder part, twice the tiles per launch,
+            # and no second stream (which a captured pass on a forked stream could not have, see _side_stream)
+            st = cur_stream.cuda_stream
+            for pair in zipped:
+                if len(pair) == 1:
+                    run_dec(pair[0])
+                else:
+                    with L.group(st) as g:
+                        run_dec(pair[0])
+                        g.next_lane()
+                        run_dec(pair[1])
+        elif side is not None:
             side.wait_stream(cur_stream)
             with torch.cuda.stream(side):
                 for op in prog.ops:
@@ -355,7 +416,7 @@ class Executor:
         extras = []
         for name in want:
             lz, (d_, h_, w_) = vals[name], vdims[name]
-            o = torch.empty((N, lz.C) + ((h_, w_) if dims == 2 else (d_, h_, w_)), dtype=torch.float32, device=dev)
+            o = L.hold_empty((N, lz.C) + ((h_, w_) if dims == 2 else (d_, h_, w_)), dtype=torch.float32, device=dev)
             ops.cl_to_planar(lz, o)
             extras.append(o)
         return logits, (S if save else None), extras
@@ -370,14 +431,23 @@ class Executor:
             gr = self.m.grad_views_of(grad_buffer) if grad_buffer is not None else self.m._grad_views()
         dev = S.x.device
         N = S.x.shape[0]
-        contrib = {}        # value name -> list of (tensor, coff)
+        contrib = {}        # value name -> list of (tensor, coff, index of the op whose backward produced it)
+        okey = {id(op): i for i, op in enumerate(prog.ops)}
+
+        def incoming(name):
+            """The gradient contributions of a value in PROGRAM order of their producers, whatever order the schedule (two
+            streams, lockstep decoders) appended them in: the sum of up to three of them is not associative in floating point,
+            and eager, captured and data-parallel runs must agree bit for bit."""
+            c = contrib.get(name)
+            return None if not c else [(t, o) for t, o, _ in sorted(c, key=lambda e: e[2])]
+
         pooled = {}         # value name -> (grad tensor, idx)
         head_g = dict(zip(prog.heads, dlogits))
         dx = None
         nsub = 2 ** dims
         # one arena for the BN-backward partial sums of every layer (per-block partial rows: nothing to zero)
         nsum = sum(ops.act_bwd_sums_size(op.cout) for op in prog.ops if op.bn)
-        sums_arena = torch.empty(nsum, dtype=torch.float32, device=dev)
+        sums_arena = L.hold_empty(nsum, dtype=torch.float32, device=dev)
         spos = [0]
 
         def take_sums(c):
@@ -389,14 +459,14 @@ class Executor:
         def scatter(op, srcs, dsrc):
             muls = S.fold.get(op.branch) if S.tables is not None else None
             if not muls:
-                return self._scatter(contrib, op, srcs, dsrc)
+                return self._scatter(contrib, op, srcs, dsrc, okey[id(op)])
             off = 0
             for name, s in zip(op.srcs, srcs):
                 o = off if op.combine == 0 else 0
                 if name in muls:        # a trunk value seen through cat((feat, mul * feat[B-U:])): fold the gradient back to B samples
-                    contrib.setdefault(name, []).append((ops.fold_perturbed(dsrc, o, s.C, muls[name], N, S.n_dec - N), 0))
+                    contrib.setdefault(name, []).append((ops.fold_perturbed(dsrc, o, s.C, muls[name], N, S.n_dec - N), 0, okey[id(op)]))
                 else:
-                    contrib.setdefault(name, []).append((dsrc, o))
+                    contrib.setdefault(name, []).append((dsrc, o, okey[id(op)]))
                 off += s.C
 
         def bwd_op(op):
@@ -405,20 +475,20 @@ class Executor:
             nonlocal dx
             k = op.kind
             if k == "pool":
-                c = contrib.get(op.out)
+                c = incoming(op.out)
                 if c:
                     assert len(c) == 1 and c[0][1] == 0
                     pooled[op.srcs[0]] = (c[0][0], S.pool_idx[op.out])
                 return
             if k == "up":
-                c = contrib.get(op.out)
+                c = incoming(op.out)
                 if c:
                     assert len(c) == 1
                     src = V[op.srcs[0]]
                     d, h, w = S.dims[op.srcs[0]]
-                    o = torch.empty(n, d, h, w, src.C, dtype=dtype, device=dev)
+                    o = L.hold_empty(n, d, h, w, src.C, dtype=dtype, device=dev)
                     ops.upsample2x_bwd(c[0][0], c[0][1], src.C, o, dims=dims)
-                    contrib.setdefault(op.srcs[0], []).append((o, 0))
+                    contrib.setdefault(op.srcs[0], []).append((o, 0, okey[id(op)]))
                 return
             # ---- gradient w.r.t. the raw output of this conv
             if op.head:
@@ -426,12 +496,12 @@ class Executor:
                 if dl is None:
                     return
                 gd = S.dims[op.out]
-                g16 = torch.empty((n,) + gd + (16,), dtype=dtype, device=dev)
+                g16 = L.hold_empty((n,) + gd + (16,), dtype=dtype, device=dev)
                 ops.planar_to_cl(dl, g16, cpad=16)
                 g = Lazy(g16)
                 kn_valid = op.cout
             else:
-                c = contrib.get(op.out)
+                c = incoming(op.out)
                 pl = pooled.get(op.out)
                 if not c and pl is None:
                     return
@@ -442,7 +512,7 @@ class Executor:
                 if plain and pl is None and len(c) == 1:
                     g = Lazy(c[0][0], C=v.C, coff=c[0][1])
                 else:
-                    gout = torch.empty((n,) + gd + (v.C,), dtype=dtype, device=dev)
+                    gout = L.hold_empty((n,) + gd + (v.C,), dtype=dtype, device=dev)
                     kw = {}
                     if op.bn:
                         if S.train:
@@ -453,7 +523,7 @@ class Executor:
                             rm, rv = sd[op.bn + ".running_mean"], sd[op.bn + ".running_var"]
                             kw = dict(bn_mode=2)
                             if need_wgrad:
-                                istd = self.m._eval_invstd(op.bn, rv)
+                                istd = L.hold(self.m._eval_invstd(op.bn, rv))      # a torch temporary: see _lib.hold
                                 kw.update(mean=rm, invstd=istd, gamma=sd[op.bn + ".weight"])
                         if need_wgrad:
                             kw.update(dgamma=gr[op.bn + ".weight"], dbeta=gr[op.bn + ".bias"])
@@ -467,7 +537,7 @@ class Executor:
                 gt = g.raw if (g.coff == 0 and g.C == g.ld) else None
                 assert gt is not None
                 if need_dx:
-                    dx = torch.empty_like(S.x)      # [n, 1, *spatial] fp32 == planar output with one channel
+                    dx = L.hold_empty_like(S.x)      # [n, 1, *spatial] fp32 == planar output with one channel
                     wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
                     ops.conv_fwd([g], wp, None, 1, dx, grid=(n, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=dims,
                                  out_planar=True, out_f32=True)
@@ -489,7 +559,7 @@ class Executor:
                     ops.wgrad(srcs, g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
                               ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid)
                 wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
-                dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
                 scatter(op, srcs, dsrc)
             elif k == "down":
@@ -498,7 +568,7 @@ class Executor:
                     ops.wgrad(srcs, g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
                               ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None)
                 wp = self._pack(op, L.PACK_DOWN_DGRAD, dtype, sd)
-                dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, nsub * ctot, dsrc, grid=(n,) + gdd, in_dims=gdd, ksize=1, stride=1, dims=dims,
                              out_mode=1, out_cn=ctot)
                 scatter(op, srcs, dsrc)
@@ -511,14 +581,29 @@ class Executor:
                     if op.b:
                         ops.channel_sum(g, gr[op.b])
                 wp = self._pack(op, L.PACK_DECONV_DGRAD, dtype, sd)
-                dsrc = torch.empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=fine, ksize=2, stride=2, dims=dims)
                 scatter(op, srcs, dsrc)
         # ---- schedule: the decoders' backward passes side by side, then the shared trunk
         cur_stream = torch.cuda.current_stream()
         rev = list(reversed(prog.ops))
-        side = self._side_stream(cur_stream) if len({op.branch for op in prog.ops}) > 2 else None
-        if side is not None:
+        nbr = len({op.branch for op in prog.ops})
+        side = self._side_stream(cur_stream) if (nbr > 2 and grouping_mode() != 2) else None
+        zipped = self._zipped() if (side is None and nbr == 3 and grouping_mode() != 0) else None
+        if zipped is not None:
+            st = cur_stream.cuda_stream
+            for pair in reversed(zipped):
+                if len(pair) == 1:
+                    bwd_op(pair[0])
+                else:
+                    with L.group(st) as g:
+                        bwd_op(pair[0])
+                        g.next_lane()
+                        bwd_op(pair[1])
+            for op in rev:
+                if op.branch == 0:
+                    bwd_op(op)
+        elif side is not None:
             side.wait_stream(cur_stream)
             with torch.cuda.stream(side):
                 for op in rev:
@@ -537,15 +622,15 @@ class Executor:
         return dx
 
     @staticmethod
-    def _scatter(contrib, op, srcs, dsrc):
+    def _scatter(contrib, op, srcs, dsrc, key=0):
         if op.combine == 0:
             off = 0
             for name, s in zip(op.srcs, srcs):
-                contrib.setdefault(name, []).append((dsrc, off))
+                contrib.setdefault(name, []).append((dsrc, off, key))
                 off += s.C
         else:
             for name in op.srcs:
-                contrib.setdefault(name, []).append((dsrc, 0))
+                contrib.setdefault(name, []).append((dsrc, 0, key))
 
 
 class Rng:

@@ -60,7 +60,7 @@ def pack_weights(w, kind, dtype, cin, cout, taps):
     p.w, p.kind, p.Cin, p.Cout, p.taps = w.data_ptr(), kind, cin, cout, taps
     p.dtype = L.F32 if dtype == torch.float32 else L.BF16
     nbytes = L.size_of("chap_pack_size", p)
-    out = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    out = L.hold_empty(nbytes, dtype=torch.uint8, device=w.device)
     p.out = out.data_ptr()
     L.call("chap_pack_weights", p, _stream())
     return out
@@ -94,7 +94,7 @@ def stats_size(clog):
 
 
 def stats_buffer(clog, device):
-    return torch.empty(stats_size(clog), dtype=torch.float32, device=device)
+    return L.hold_empty(stats_size(clog), dtype=torch.float32, device=device)
 
 
 def stats_totals(stats, clog, creal=None):
@@ -134,7 +134,7 @@ def conv_c1_bwd(g, w, x, *, dims, dx=None, dw=None, db=None):
     p.dims, p.Cout, p.dtype = dims, g.shape[-1], dt(g)
     ws = None
     if dw is not None or db is not None:
-        ws = torch.empty(L.size_of("chap_conv_c1_bwd_ws", p), dtype=torch.uint8, device=g.device)
+        ws = L.hold_empty(L.size_of("chap_conv_c1_bwd_ws", p), dtype=torch.uint8, device=g.device)
         p.ws = ws.data_ptr()
     L.call("chap_conv_c1_bwd", p, _stream())
 
@@ -154,7 +154,7 @@ def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine
     p.kc_valid, p.kn_valid = kc_valid, kn_valid
     p.dtype = dt(b.raw)
     nbytes = L.size_of("chap_wgrad_ws", p)
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dw.device)
+    ws = L.hold_empty(max(nbytes, 16), dtype=torch.uint8, device=dw.device)
     p.ws, p.ws_bytes = ws.data_ptr(), nbytes
     L.call("chap_wgrad", p, _stream())
 
@@ -230,7 +230,7 @@ def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=
         bn_mode = 1 if mean is not None else 0
     need_reduce = bn_mode == 1 or (bn_mode == 2 and (dgamma is not None or dbeta is not None))
     if need_reduce and sums is None:
-        sums = torch.empty(act_bwd_sums_size(lazy.C), dtype=torch.float32, device=gout.device)
+        sums = L.hold_empty(act_bwd_sums_size(lazy.C), dtype=torch.float32, device=gout.device)
     p = _act_bwd_params(lazy, grads, g_pool, pool_idx, mean, invstd, gamma, sums, gout, dgamma, dbeta, count)
     p.bn = bn_mode
     if need_reduce:
@@ -246,7 +246,7 @@ def act_bwd_sums_size(c):
 def channel_sum(lazy, out):
     p = L.ChanSumParams()
     lazy.fill(p.r)
-    ws = torch.empty(L.CHANSUM_SLOTS * lazy.C, dtype=torch.float32, device=out.device)
+    ws = L.hold_empty(L.CHANSUM_SLOTS * lazy.C, dtype=torch.float32, device=out.device)
     p.ws = ws.data_ptr()
     p.out, p.npix, p.pix_per_sample, p.dtype = out.data_ptr(), lazy.raw[..., 0].numel(), lazy.raw[0, ..., 0].numel(), dt(lazy.raw)
     L.call("chap_channel_sum", p, _stream())
@@ -275,8 +275,8 @@ def mix_loss_fwd(logits, target_a, target_b, mask, w_a, w_b, smooth=1e-10, k_dic
     target_b / mask may be None (mask of ones); (k_dice, k_ce) = (0, 0) selects mix_loss's 0.5 / 0.5."""
     N, Cc = logits.shape[0], logits.shape[1]
     p = L.MixLossParams()
-    acc = torch.empty((1 + L.LOSS_SLOTS) * 2 * (2 + 3 * Cc), dtype=torch.float32, device=logits.device)     # row 0 = totals (read by mix_loss_bwd)
-    loss = torch.empty(3, dtype=torch.float32, device=logits.device)
+    acc = L.hold_empty((1 + L.LOSS_SLOTS) * 2 * (2 + 3 * Cc), dtype=torch.float32, device=logits.device)     # row 0 = totals (read by mix_loss_bwd)
+    loss = L.hold_empty(3, dtype=torch.float32, device=logits.device)
     p.logits, p.target_a, p.target_b, p.mask = logits.data_ptr(), target_a.data_ptr(), _p(target_b), _p(mask)
     p.w_a, p.w_b, p.acc, p.loss = w_a, w_b, acc.data_ptr(), loss.data_ptr()
     p.N, p.C, p.P, p.smooth, p.k_dice, p.k_ce = N, Cc, logits[0, 0].numel(), smooth, k_dice, k_ce
@@ -299,11 +299,11 @@ def pseudo_block(logits1, logits2, want_soft=True):
     N, Cc = logits1.shape[0], logits1.shape[1]
     sp = logits1.shape[2:]
     dev = logits1.device
-    soft1 = torch.empty_like(logits1) if want_soft else None
-    soft2 = torch.empty_like(logits2) if want_soft else None
-    arg1 = torch.empty((N,) + tuple(sp), dtype=torch.int64, device=dev)
-    arg2 = torch.empty_like(arg1)
-    know = torch.empty((N,) + tuple(sp), dtype=torch.float32, device=dev)
+    soft1 = L.hold_empty_like(logits1) if want_soft else None
+    soft2 = L.hold_empty_like(logits2) if want_soft else None
+    arg1 = L.hold_empty((N,) + tuple(sp), dtype=torch.int64, device=dev)
+    arg2 = L.hold_empty_like(arg1)
+    know = L.hold_empty((N,) + tuple(sp), dtype=torch.float32, device=dev)
     p = L.PseudoParams()
     p.logits1, p.logits2, p.soft1, p.soft2 = logits1.data_ptr(), logits2.data_ptr(), _p(soft1), _p(soft2)
     p.arg1, p.arg2, p.knowledge = arg1.data_ptr(), arg2.data_ptr(), know.data_ptr()
@@ -322,7 +322,7 @@ def kl_fwd_bwd(logits, targets, loss, dlogits=(None, None), gscale=1.0, gscale_d
     p.mode = DIST_MODES[mode]
     Cc = logits[0].shape[1]
     if loss is not None or p.mode == 1:
-        ws = torch.empty((1 + L.LOSS_SLOTS) * 2 * (3 * Cc + 1), dtype=torch.float32, device=logits[0].device)
+        ws = L.hold_empty((1 + L.LOSS_SLOTS) * 2 * (3 * Cc + 1), dtype=torch.float32, device=logits[0].device)
         p.ws = ws.data_ptr()
     for h in range(2):
         p.logits[h], p.target[h], p.dlogits[h] = logits[h].data_ptr(), targets[h].data_ptr(), _p(dlogits[h])
@@ -333,7 +333,7 @@ def kl_fwd_bwd(logits, targets, loss, dlogits=(None, None), gscale=1.0, gscale_d
 
 def l2_normalize(x, out, eps=1e-8):
     p = L.L2NormParams()
-    ws = torch.empty(x.shape[0] * L.L2NORM_SLOTS, dtype=torch.float32, device=x.device)
+    ws = L.hold_empty(x.shape[0] * L.L2NORM_SLOTS, dtype=torch.float32, device=x.device)
     p.in_, p.out, p.N, p.P, p.eps, p.ws = x.data_ptr(), out.data_ptr(), x.shape[0], x[0].numel(), eps, ws.data_ptr()
     L.call("chap_l2_normalize", p, _stream())
 
@@ -371,7 +371,7 @@ def sample_channel_sum(lazy, nchunk=32):
     p = L.SampleChanSumParams()
     lazy.fill(p.r)
     N = lazy.raw.shape[0]
-    partial = torch.empty(N, nchunk, lazy.C, dtype=torch.float32, device=lazy.raw.device)
+    partial = L.hold_empty(N, nchunk, lazy.C, dtype=torch.float32, device=lazy.raw.device)
     p.partial, p.N, p.nchunk, p.pix_per_sample, p.dtype = partial.data_ptr(), N, nchunk, lazy.raw[0, ..., 0].numel(), dt(lazy.raw)
     L.call("chap_sample_channel_sum", p, _stream())
     return partial
@@ -395,7 +395,7 @@ def channel_drop(mul1, mul2, u1, u2, B, mode, *, pool_partial=None, npix=1, grad
 def fold_perturbed(g, coff, Cc, mul, B, U):
     """Adjoint of cat((feat, mul * feat[B-U:])): g [B + U, ..., ld] (channels [coff, coff + Cc)) -> [B, ..., Cc]."""
     p = L.FoldParams()
-    out = torch.empty((B,) + tuple(g.shape[1:-1]) + (Cc,), dtype=g.dtype, device=g.device)
+    out = L.hold_empty((B,) + tuple(g.shape[1:-1]) + (Cc,), dtype=g.dtype, device=g.device)
     p.g, p.mul, p.out = g.data_ptr(), _p(mul), out.data_ptr()
     p.B, p.U, p.C, p.ld, p.coff = B, U, Cc, g.shape[-1], coff
     p.pix_per_sample, p.dtype = g[0, ..., 0].numel(), dt(g)
@@ -422,12 +422,12 @@ def box_mask(mask, box):
 def largest_cc(labels, num_classes):
     """labels int64 [N, H, W] (8-connectivity) or [N, D, H, W] (26-connectivity) -> same shape, keeping the
     largest connected component per (sample, class > 0)."""
-    out = torch.empty_like(labels)
+    out = L.hold_empty_like(labels)
     p = L.LccParams()
     p.labels, p.out = labels.data_ptr(), out.data_ptr()
     p.N, p.H, p.W, p.num_classes = labels.shape[0], labels.shape[-2], labels.shape[-1], num_classes
     p.D = labels.shape[1] if labels.dim() == 4 else 1
-    ws = torch.empty(L.size_of("chap_lcc_ws", p), dtype=torch.uint8, device=labels.device)
+    ws = L.hold_empty(L.size_of("chap_lcc_ws", p), dtype=torch.uint8, device=labels.device)
     p.ws = ws.data_ptr()
     L.call("chap_largest_cc", p, _stream())
     return out
@@ -439,8 +439,8 @@ def diff_mask(p1, p2, knowledge, scale, topk):
         n, d, h, w = knowledge.shape
         return diff_mask(p1.reshape(n, d * h, w), p2.reshape(n, d * h, w), knowledge.reshape(n, d * h, w), scale, topk).reshape(n, d, h, w)
     N, H, W = knowledge.shape
-    out = torch.empty(N, H, W, dtype=torch.float32, device=knowledge.device)
-    ws = torch.empty(N * (H // scale) * (W // scale) + N, dtype=torch.float32, device=knowledge.device)
+    out = L.hold_empty(N, H, W, dtype=torch.float32, device=knowledge.device)
+    ws = L.hold_empty(N * (H // scale) * (W // scale) + N, dtype=torch.float32, device=knowledge.device)
     p = L.DiffMaskParams()
     p.p1, p.p2, p.knowledge, p.out, p.pooled_ws = p1.data_ptr(), p2.data_ptr(), knowledge.data_ptr(), out.data_ptr(), ws.data_ptr()
     p.N, p.H, p.W, p.scale, p.topk = N, H, W, scale, topk
@@ -474,8 +474,8 @@ def ensemble_argmax(logits1, logits2, mode, want_prob=False):
     ref = logits1 if logits1 is not None else logits2
     N, Cc = ref.shape[0], ref.shape[1]
     p = L.EnsembleParams()
-    label = torch.empty((N,) + tuple(ref.shape[2:]), dtype=torch.uint8, device=ref.device)
-    prob = torch.empty_like(ref) if want_prob else None
+    label = L.hold_empty((N,) + tuple(ref.shape[2:]), dtype=torch.uint8, device=ref.device)
+    prob = L.hold_empty_like(ref) if want_prob else None
     p.logits1, p.logits2, p.prob, p.label = _p(logits1), _p(logits2), _p(prob), label.data_ptr()
     p.N, p.C, p.P, p.mode = N, Cc, ref[0, 0].numel(), ENSEMBLE_MODES[mode] if isinstance(mode, str) else mode
     L.call("chap_ensemble_argmax", p, _stream())
@@ -495,7 +495,7 @@ def window_accumulate(logits, origins, score, cnt):
 def window_finalize(score, cnt):
     """score /= cnt in place; returns label uint8 [W, H, D] = argmax over classes."""
     p = L.WindowFinParams()
-    label = torch.empty(cnt.shape, dtype=torch.uint8, device=cnt.device)
+    label = L.hold_empty(cnt.shape, dtype=torch.uint8, device=cnt.device)
     p.score, p.cnt, p.label, p.C, p.P = score.data_ptr(), cnt.data_ptr(), label.data_ptr(), score.shape[0], cnt.numel()
     L.call("chap_window_finalize", p, _stream())
     return label

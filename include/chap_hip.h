@@ -35,6 +35,8 @@
  *      sums, the loss accumulators (chap_mix_loss_*: acc is a workspace of partial rows), chap_kl_fwd_bwd (ws),
  *      chap_channel_sum (ws), chap_l2_normalize (ws = N * CHAP_L2NORM_SLOTS floats) likewise.  chap_kl_fwd_bwd: `mode`
  *      (KL or Dice distance).  chap_grad_sim.
+ *   5  chap_group_begin / chap_group_next_lane / chap_group_end: grouped launches of same-shaped layers (the two decoders of a
+ *      DualDecoder, two passes of one network) -- one grid instead of 2-4, bit-identical results.
  */
 #ifndef CHAP_HIP_H
 #define CHAP_HIP_H
@@ -46,7 +48,7 @@
 extern "C" {
 #endif
 
-#define CHAP_ABI_VERSION 4
+#define CHAP_ABI_VERSION 5
 #define CHAP_STATS_MAX_SLOTS 1024  /* per-block partial slots of the BatchNorm statistics (one per persistent conv block) */
 #define CHAP_STATS_HDR 4           /* floats in front of the slots; word 0 = number of slots in use (int32)                */
 #define CHAP_ACT_BWD_SLOTS 1024    /* per-block partial slots of the BN-backward sums                                      */
@@ -417,6 +419,29 @@ int chap_fold_perturbed(const chap_fold_params* p, void* stream);
  * similarity).  One wave per channel, fixed-order fp64 reduction. */
 typedef struct { const float* gl; const float* gu; float* score; int32_t C, K; float ema; } chap_gradsim_params;
 int chap_grad_sim(const chap_gradsim_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped launches.  An iteration of the hot path is a chain of ~600 dependent launches of kernels that do 2-5 us of work
+ * in 8-20 us (fixed cost: launch gap, block prologue, one cold memory round trip), and it contains the SAME layer several
+ * times on different tensors: the two decoders of DualDecoder / DualDecoder3d (unet.py:277-292: decoder1 and decoder2 share every
+ * ConvBlock shape; vnet.py:234-238), and independent passes of one network (pass A on the unlabeled half, train_ours_2D.py:314,
+ * and the first VAT forward, :372, meet only in the distance kernel).
+ *
+ *     chap_group_begin(stream);   ...calls of lane 0...   chap_group_next_lane();   ...calls of lane 1...   chap_group_end();
+ *
+ * Between begin and end the entry points of the networks' forward / backward path (chap_conv_fwd, chap_conv_c1_*, chap_wgrad,
+ * chap_bn_finalize, chap_bn_eval_affine, chap_act_bwd_*, chap_act_pool2, chap_upsample2x*, chap_planar_to_cl, chap_cl_to_planar,
+ * chap_channel_sum, chap_keep_mask, chap_chan_mask, chap_fold_perturbed) check their arguments and RECORD their launches instead
+ * of issuing them; chap_group_end issues, for j = 0, 1, ..., the j-th recorded launch of every lane -- as ONE grid (gridDim.z = lanes,
+ * up to 4) when they resolved to the same kernel instance and launch geometry, else one after the other in lane order.  Every block
+ * does exactly the work it would do in a launch of its own (same tiles, same reduction slots): results are bit-identical to the
+ * ungrouped calls.  The lanes must be independent of each other (no lane reads what another lane of the same region writes);
+ * within a lane the order of the calls is kept.  All calls of a region go to the stream given to chap_group_begin; any other
+ * entry point of this library fails with CHAP_EUNSUPPORTED inside a region.  State is thread-local; regions do not nest.
+ * chap_group_end returns the number of grids launched (>= 0) or a negative CHAP_E* code. */
+int chap_group_begin(void* stream);
+int chap_group_next_lane(void);
+int chap_group_end(void);
 
 /* Bandwidth calibration helper (tools/membw.py): grid-stride float4 copy with `blocks` blocks of 256. */
 int chap_debug_copy(const void* src, void* dst, int64_t bytes, int32_t blocks, void* stream);

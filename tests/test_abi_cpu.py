@@ -29,9 +29,10 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 35
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.chap_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.chap_abi_version() == _lib.ABI_VERSION == 5
     # every entry point bound in the ctypes tables is declared in the header and vice versa
-    bound = set(_lib._SIGS) | set(_lib._SIZE_FNS) | {"chap_last_error", "chap_abi_version", "chap_debug_copy", "chap_pack_describe", "chap_pack_multi"}
+    bound = set(_lib._SIGS) | set(_lib._SIZE_FNS) | {"chap_last_error", "chap_abi_version", "chap_debug_copy", "chap_pack_describe", "chap_pack_multi",
+                                                                "chap_group_begin", "chap_group_next_lane", "chap_group_end"}
     assert bound == set(names), (bound ^ set(names))
 
 
