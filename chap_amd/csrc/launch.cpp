@@ -72,3 +72,11 @@ extern "C" int chap_group_end(void) {
     G.lanes.clear();
     return rc == CHAP_OK ? launched : rc;
 }
+
+namespace { thread_local const float* g_stats_ptr = nullptr; thread_local int g_stats_slots = 0; }
+void chap_note_stats_slots(const float* stats, int slots) { g_stats_ptr = stats; g_stats_slots = slots; }
+int chap_known_stats_slots(const float* stats) {      // one-shot: only the finalize call right behind the conv may use the note
+    const int n = (stats != nullptr && stats == g_stats_ptr) ? g_stats_slots : 0;
+    g_stats_ptr = nullptr;
+    return n;
+}

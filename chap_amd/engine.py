@@ -86,6 +86,32 @@ def zip_branches(a_ops, b_ops):
     return out
 
 
+def drive(gens, stream):
+    """Run step generators (Executor.forward_steps / backward_steps) in lockstep: at every step the lanes of all generators are
+    enqueued inside ONE grouped launch region (their same-shaped kernels become one grid), a single lane directly.  All generators
+    must make the same number of steps (same program, same options).  Returns their return values."""
+    results, done = [None] * len(gens), 0
+    while True:
+        lanes = []
+        for i, g in enumerate(gens):
+            try:
+                lanes += next(g)
+            except StopIteration as e:
+                results[i], done = e.value, done + 1
+        if done:
+            if done != len(gens) or lanes:
+                raise RuntimeError("chap_amd: passes driven in lockstep made different numbers of steps")
+            return results
+        if len(lanes) == 1:
+            lanes[0]()
+        else:
+            with L.group(stream) as region:
+                for k, f in enumerate(lanes):
+                    if k:
+                        region.next_lane()
+                    f()
+
+
 def grouping_mode():
     """CHAP_GROUP (lab / A-B switch): 0 = never group (round 2: decoders back to back where a pass cannot fork), 1 (default) = group the
     two decoders' same-shaped layers in the passes that cannot fork a second stream, 2 = group in every pass (no second stream)."""
@@ -201,9 +227,17 @@ class Executor:
         return self._ensure_packed(dtype, sd)["bufs"][(op.w, kind)]
 
     # ---------------------------------------------------------------- forward
-    def forward(self, x, *, train, dtype, save, update_stats=True, drop_masks=None, rng=None, want=(), perturb=None):
+    def forward(self, x, **kw):
         """x: fp32 [N, 1, *spatial] contiguous. Returns (list of planar fp32 logits, Saved|None, extras):
         extras = the activated values named in `want`, materialised as planar fp32 [N, C, *spatial]."""
+        return drive([self.forward_steps(x, **kw)], torch.cuda.current_stream().cuda_stream)[0]
+
+    def forward_steps(self, x, *, train, dtype, save, update_stats=True, drop_masks=None, rng=None, want=(), perturb=None, lock=False):
+        """The forward pass as a generator of STEPS: each `yield` hands the driver (engine.drive) the lanes of one step -- a list
+        of callables that enqueue the step's kernels, one per lane (one op; or the same-shaped ops of the two decoders) -- and the
+        generator's return value is forward()'s.  Several passes of one network driven together run in lockstep: the lanes of
+        their steps become ONE grouped launch region each (chap_hip.h, chap_group_*).  lock: this pass is one of several driven
+        together (or must not use a second stream): the decoders run in lockstep, never on a forked stream."""
         prog, sd, dims = self.prog, self._sd(), self.prog.dims
         dev = x.device
         N = x.shape[0]
@@ -246,7 +280,9 @@ class Executor:
         # two decoders: on a second stream where this pass may fork one (eager; under capture only from the capture's origin
         # stream), otherwise in lockstep with grouped launches.  CHAP_GROUP=2 (lab): lockstep everywhere.
         side = self._side_stream(cur_stream) if (len(branches) > 2 and grouping_mode() != 2) else None
-        zipped = self._zipped() if (side is None and len(branches) == 3 and grouping_mode() != 0) else None
+        if lock:
+            side = None
+        zipped = self._zipped() if (side is None and len(branches) == 3 and (lock or grouping_mode() != 0)) else None
 
         # Dropout seeds are drawn HERE, in program order: the order in which the ops are ISSUED depends on whether this pass
         # may fork its second decoder (eager / captured, which stream), and a seed must not (round 2: the early VAT pass drew
@@ -373,7 +409,7 @@ class Executor:
         # ---- schedule: trunk, then the decoders side by side (second decoder on a forked stream)
         for op in prog.ops:
             if op.branch == 0:
-                run_op(op)
+                yield [lambda op=op: run_op(op)]
         if perturb is not None:
             # channel-level perturbation (FilterDropout.perform_dropout): every decoder gets its own version of the
             # trunk's values -- a larger batch with per-(sample, channel) multipliers -- and runs on that batch
@@ -389,15 +425,8 @@ class Executor:
             # the two decoders in lockstep: same-shaped layers (ConvBlock convs, their BatchNorm finalizes, the heads) are the two lanes
             # of ONE grouped launch (chap_hip.h, chap_group_*): half the launches of the decoder part, twice the tiles per launch,
             # and no second stream (which a captured pass on a forked stream could not have, see _side_stream)
-            st = cur_stream.cuda_stream
             for pair in zipped:
-                if len(pair) == 1:
-                    run_dec(pair[0])
-                else:
-                    with L.group(st) as g:
-                        run_dec(pair[0])
-                        g.next_lane()
-                        run_dec(pair[1])
+                yield [lambda op=op: run_dec(op) for op in pair]
         elif side is not None:
             side.wait_stream(cur_stream)
             with torch.cuda.stream(side):
@@ -411,7 +440,7 @@ class Executor:
         else:
             for op in prog.ops:
                 if op.branch != 0:
-                    run_dec(op)
+                    yield [lambda op=op: run_dec(op)]
         logits = [outs[h] for h in prog.heads]
         extras = []
         for name in want:
@@ -422,9 +451,13 @@ class Executor:
         return logits, (S if save else None), extras
 
     # ---------------------------------------------------------------- backward
-    def backward(self, S, dlogits, *, dtype, need_wgrad, need_dx, grad_buffer=None):
+    def backward(self, S, dlogits, **kw):
         """dlogits: list (per head) of planar fp32 gradients or None. Accumulates parameter gradients
         into the module's flat grad views; returns dx (fp32, shape of x) or None."""
+        return drive([self.backward_steps(S, dlogits, **kw)], torch.cuda.current_stream().cuda_stream)[0]
+
+    def backward_steps(self, S, dlogits, *, dtype, need_wgrad, need_dx, grad_buffer=None, lock=False):
+        """The backward pass as a generator of steps (see forward_steps); returns dx."""
         prog, sd, dims = self.prog, self._sd(), self.prog.dims
         gr = None
         if need_wgrad:
@@ -589,20 +622,15 @@ class Executor:
         rev = list(reversed(prog.ops))
         nbr = len({op.branch for op in prog.ops})
         side = self._side_stream(cur_stream) if (nbr > 2 and grouping_mode() != 2) else None
-        zipped = self._zipped() if (side is None and nbr == 3 and grouping_mode() != 0) else None
+        if lock:
+            side = None
+        zipped = self._zipped() if (side is None and nbr == 3 and (lock or grouping_mode() != 0)) else None
         if zipped is not None:
-            st = cur_stream.cuda_stream
             for pair in reversed(zipped):
-                if len(pair) == 1:
-                    bwd_op(pair[0])
-                else:
-                    with L.group(st) as g:
-                        bwd_op(pair[0])
-                        g.next_lane()
-                        bwd_op(pair[1])
+                yield [lambda op=op: bwd_op(op) for op in pair]
             for op in rev:
                 if op.branch == 0:
-                    bwd_op(op)
+                    yield [lambda op=op: bwd_op(op)]
         elif side is not None:
             side.wait_stream(cur_stream)
             with torch.cuda.stream(side):
@@ -618,7 +646,7 @@ class Executor:
                     bwd_op(op)
         else:
             for op in rev:
-                bwd_op(op)
+                yield [lambda op=op: bwd_op(op)]
         return dx
 
     @staticmethod

@@ -317,3 +317,42 @@ def test_chapstep_streams_are_distinct():
         handles = [t.cuda_stream for t in (s._side, s._d2, s._pre, s._cap)]
         assert len(set(handles)) == 4 and 0 not in handles and torch.cuda.current_stream().cuda_stream not in handles
     del keep
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_lockstep_schedule_equals_the_stream_parallel_schedule(dims):
+    """Round 3: the iteration as three lockstep phases with grouped launches (ChapStep._iteration_lockstep, the default) against the
+    round-2 schedule (passes on three streams, one launch per op; args lockstep=False), from one state with the same injected
+    randomness: a grouped launch runs the same blocks on the same data as the separate launches, so losses, parameters,
+    BatchNorm buffers and momentum are equal BIT FOR BIT."""
+    from chap_amd import _lib as L
+    from chap_amd.networks import DualDecoder3d
+    from tests.iteration_parity import inject_2d, inject_3d, to_dev
+    if dims == 2:
+        B, lbs, sp = 8, 4, (64, 64)
+        state = oinit.dual_decoder_2d_state(301)
+        vol, lab = ots.synthetic_batch(1337, lbs, B - lbs, *sp)
+        inj = to_dev(inject_2d(B - lbs, lbs // 2 + (B - lbs) // 2, sp[0], sp[1], 2), 2)
+        mk, box, extra = (lambda: DualDecoder(1, 4, {"decoder_type": "mcnet"})), (7, 11), {}
+    else:
+        B, lbs, sp = 4, 2, (16, 32, 16)
+        state = oinit.dual_decoder_3d_state(401)
+        vol, lab = ots.synthetic_batch_3d(1337, lbs, B - lbs, *sp)
+        inj = to_dev(inject_3d(B - lbs, lbs // 2 + (B - lbs) // 2, sp, 2), 3)
+        mk, box, extra = (lambda: DualDecoder3d(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)), (2, 5, 3), {"num_classes": 2}
+    res = {}
+    for lock in (True, False):
+        m = mk().to(DEV).train()
+        m.load_state_dict(state, strict=True)
+        step = ChapStep(m, dict(dict(labeled_bs=lbs, batch_size=B, vat_iters=2, lockstep=lock), **extra))
+        step.iter_num = 4500
+        n0 = L.group.launched
+        out = step.step(vol.to(DEV), lab.to(DEV), box_yx=box, inject=inj)
+        torch.cuda.synchronize()
+        res[lock] = (out, {k: v.clone() for k, v in m.state_dict().items()}, step.opt.mom.clone(), L.group.launched - n0)
+    (oa, sa, ma, na), (ob, sb, mb, nb) = res[True], res[False]
+    for x, y in zip(oa["mix_losses"] + [oa["vat_loss"]], ob["mix_losses"] + [ob["vat_loss"]]):
+        assert torch.equal(x, y), (x, y)
+    assert [k for k in sa if not torch.equal(sa[k], sb[k])] == []
+    assert torch.equal(ma, mb)
+    assert na > 100                                         # grouped regions really ran (and far more of them than in the stream-parallel schedule)
