@@ -462,26 +462,42 @@ extern "C" int chap_ensemble_argmax(const chap_ensemble_params* p, void* stream)
     return CHAP_OK;
 }
 
+// Gather form, fixed order: one thread per voxel of the volume adds the soft-max scores of the patches that cover it in PATCH
+// ORDER k = 0, 1, ... -- the order of the reference's loop (test_3D_util.py:62-69) -- with plain loads and stores: no float atomics,
+// the score map does not depend on scheduling (round 2 scattered the patches with atomicAdd: last-bit differences between runs).
 __global__ __launch_bounds__(256) void window_accumulate_kernel(const chap_window_acc_params P) {
-    const long pvox = (long)P.pw * P.ph * P.pd, total = (long)P.npatch * pvox;
+    const long pvox = (long)P.pw * P.ph * P.pd;
     const long vol = (long)P.W * P.H * P.D;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int k = (int)(i / pvox); long r = i % pvox;
-        const int z = (int)(r % P.pd); r /= P.pd;
-        const int y = (int)(r % P.ph); const int x = (int)(r / P.ph);
-        const float* lg = P.logits + (long)k * P.C * pvox + (i % pvox);
-        float v[INFER_MAXC];
-        for (int c = 0; c < P.C; ++c) v[c] = lg[c * pvox];
-        softmax_c(v, P.C);
-        const long o = ((long)(P.origins[3 * k] + x) * P.H + (P.origins[3 * k + 1] + y)) * P.D + (P.origins[3 * k + 2] + z);
-        for (int c = 0; c < P.C; ++c) atomicAdd(P.score + c * vol + o, v[c]);
-        atomicAdd(P.cnt + o, 1.f);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < vol; i += (long)gridDim.x * 256) {
+        const int z = (int)(i % P.D); const long r = i / P.D;
+        const int y = (int)(r % P.H); const int x = (int)(r / P.H);
+        float acc[INFER_MAXC], cn = 0.f;
+        bool touched = false;
+        for (int k = 0; k < P.npatch; ++k) {
+            const int lx = x - P.origins[3 * k], ly = y - P.origins[3 * k + 1], lz = z - P.origins[3 * k + 2];
+            if ((unsigned)lx >= (unsigned)P.pw || (unsigned)ly >= (unsigned)P.ph || (unsigned)lz >= (unsigned)P.pd) continue;
+            if (!touched) {
+                for (int c = 0; c < P.C; ++c) acc[c] = P.score[c * vol + i];
+                cn = P.cnt[i];
+                touched = true;
+            }
+            const float* lg = P.logits + (long)k * P.C * pvox + ((long)lx * P.ph + ly) * P.pd + lz;
+            float v[INFER_MAXC];
+            for (int c = 0; c < P.C; ++c) v[c] = lg[c * pvox];
+            softmax_c(v, P.C);
+            for (int c = 0; c < P.C; ++c) acc[c] += v[c];
+            cn += 1.f;
+        }
+        if (touched) {
+            for (int c = 0; c < P.C; ++c) P.score[c * vol + i] = acc[c];
+            P.cnt[i] = cn;
+        }
     }
 }
 extern "C" int chap_window_accumulate(const chap_window_acc_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->logits && p->origins && p->score && p->cnt && p->npatch > 0 && p->C >= 1 && p->C <= INFER_MAXC, "chap_window_accumulate: bad argument");
     CHAP_CHECK_ARG(p->pw > 0 && p->ph > 0 && p->pd > 0 && p->pw <= p->W && p->ph <= p->H && p->pd <= p->D, "chap_window_accumulate: patch larger than the volume");
-    hipLaunchKernelGGL(window_accumulate_kernel, dim3(loss_blocks((long)p->npatch * p->pw * p->ph * p->pd)), dim3(256), 0, (hipStream_t)stream, *p);
+    hipLaunchKernelGGL(window_accumulate_kernel, dim3(loss_blocks((long)p->W * p->H * p->D)), dim3(256), 0, (hipStream_t)stream, *p);
     CHAP_LAUNCH_CHECK("chap_window_accumulate");
     return CHAP_OK;
 }

@@ -369,8 +369,8 @@ int chap_ensemble_argmax(const chap_ensemble_params* p, void* stream);
 
 /* chap_window_accumulate: score[:, xs:xs+pw, ys:ys+ph, zs:zs+pd] += softmax(logits), cnt[same] += 1
  * (test_3D_util.py:62-69) for `npatch` patches at once: logits fp32 [npatch][C][pw][ph][pd], origins int32
- * [npatch][3]; score fp32 [C][W][H][D], cnt fp32 [W][H][D].  Overlapping patches of ONE call are summed with
- * float atomics in unspecified order (the reference's order is the loop order: last-bit differences).
+ * [npatch][3]; score fp32 [C][W][H][D], cnt fp32 [W][H][D].  Gather form: every voxel adds the patches that cover it in patch
+ * order k = 0, 1, ... (the order of the reference's loop), plain loads and stores -- no float atomics, bitwise reproducible.
  * chap_window_finalize: label = argmax_c score/cnt (:70-71), uint8 [W][H][D]; score is normalised in place. */
 typedef struct { const float* logits; const int32_t* origins; float* score; float* cnt; int32_t npatch, C; int32_t pw, ph, pd; int32_t W, H, D; } chap_window_acc_params;
 int chap_window_accumulate(const chap_window_acc_params* p, void* stream);

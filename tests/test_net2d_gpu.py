@@ -100,7 +100,7 @@ def test_dualdecoder_train_injected(golden_dir, dtype):
             if np.abs(g["train64_grad_pick%d" % i]).max() < 1e-9:      # conv bias before train-mode BN: exactly 0
                 assert e < 1e-3, n
             else:
-                # float atomics in the BN statistics make the last bits run-dependent; amplified ~1e5x here
+                # fp32 rounding of the BN statistics (fixed-order sums since round 2, still fp32) is amplified ~1e5x here
                 assert e < max(4 * ref_e, 2e-2), (n, e, ref_e)
     else:
         # ill-conditioned case (32 samples per channel at the bottleneck BN): bf16 keeps the direction only

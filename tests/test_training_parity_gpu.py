@@ -122,7 +122,7 @@ def test_trained_model_dice_matches_oracle_inference():
     p_ref = predict_oracle(sd, val)
     d_ref, d_hip = dice_per_class(p_ref, gt.numpy()), dice_per_class(p_hip, gt.numpy())
     assert d_ref.mean() > 0.2, d_ref                        # the trained model really segments something (the trajectory is chaotic:
-                                                            # float-atomic BN sums x arg-max pseudo labels; 0.28 .. 0.45 over runs)
+                                                            # rounding x arg-max pseudo labels; 0.28 .. 0.45 over seeds / arithmetic)
     assert np.abs(d_ref - d_hip).max() <= 1e-3, (d_ref, d_hip)
     assert (p_ref == p_hip).mean() > 0.999
 
@@ -130,7 +130,7 @@ def test_trained_model_dice_matches_oracle_inference():
 def test_resume_continues_the_run():
     """Checkpoint / resume (build extension): 2 iterations, state_dict(), a FRESH model + ChapStep loaded from it,
     2 more iterations == 4 uninterrupted iterations (same injected randomness; BCP boxes come from numpy's RNG,
-    which the checkpoint carries).  Equality up to the float-atomic summation order of the BN statistics."""
+    which the checkpoint carries).  Bitwise: every reduction on the device has a fixed order (round 2)."""
     B, lbs, H, W = 8, 4, 64, 64
     U = B - lbs
     args = dict(labeled_bs=lbs, batch_size=B, vat_iters=1, base_lr=0.01)
