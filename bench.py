@@ -163,7 +163,9 @@ def top_instance_from_profile(cfg):
     try:
         rows = list(csv.DictReader(open(files[-1])))
         top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
-        name = re.sub(r"\(.*$", "", top["Name"]).replace("void ", "").replace("unsigned short", "bf16")
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from kname import short_name
+        name = top.get("Kernel") or short_name(top["Name"])
         return {"instance": name, "share_of_kernel_time": round(float(top["Percentage"]) / 100.0, 4), "avg_ns_in_iteration": round(float(top["AverageNs"])),
                 "source": os.path.relpath(files[-1], ROOT)}
     except Exception:

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libchap_hip.so")
+LIB_PATH = os.environ.get("CHAP_LIBPATH") or os.path.join(_HERE, "libchap_hip.so")      # CHAP_LIBPATH: a lab build of the same sources (A/B of compile-time variants)
 
 F32, BF16 = 0, 1
 STATS_MAX_SLOTS, STATS_HDR = 1024, 4          # CHAP_STATS_MAX_SLOTS, CHAP_STATS_HDR

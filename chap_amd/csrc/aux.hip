@@ -78,14 +78,26 @@ extern "C" int chap_rand_uniform(const chap_rand_params* p, void* stream) {
     CHAP_LAUNCH_CHECK("chap_rand_uniform");
     return CHAP_OK;
 }
+// 16 mask bytes per thread and store (one byte per thread was 12.6 M byte stores for the first encoder level); the value of byte i
+// depends on (seed, i) only, so any launch geometry gives the same mask.
 __device__ __forceinline__ void keepmask_kernel(const chap_keepmask_params& P) {
     const uint64_t seed = P.seed + (P.seed_dev ? *P.seed_dev * 0xD1342543DE82EF95ull : 0);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += (long)gridDim.x * blockDim.x)
-        P.keep[i] = u01(seed, i) >= P.p ? 1 : 0;
+    const long n16 = (P.n + 15) / 16;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n16; q += (long)gridDim.x * blockDim.x) {
+        const long i0 = q * 16;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j >> 2] |= (u01(seed, i0 + j) >= P.p ? 1u : 0u) << (8 * (j & 3));
+        if (i0 + 16 <= P.n && (((uintptr_t)P.keep) & 15) == 0) *(uint4*)(P.keep + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+        else for (int j = 0; j < 16 && i0 + j < P.n; ++j) P.keep[i0 + j] = (uint8_t)((w[j >> 2] >> (8 * (j & 3))) & 0xff);
+    }
 }
 extern "C" int chap_keep_mask(const chap_keepmask_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->keep, "chap_keep_mask: null argument");
-    const int nb = chap_blocks(p->n, 4096);
+    // one launch geometry for every mask of at least 1 MB (grid-stride): the masks of the five encoder levels of a pass are then the lanes
+    // of ONE grouped launch (chap_group_*)
+    const long n16 = (p->n + 15) / 16;
+    const int nb = n16 >= 256 * 256 ? 256 : (int)((n16 + 255) / 256 > 0 ? (n16 + 255) / 256 : 1);
     return chap_launch<chap_keepmask_params, keepmask_kernel, 256>(dim3(nb), dim3(256), 0, (hipStream_t)stream, *p, "chap_keep_mask");
 }
 __device__ __forceinline__ void chanmask_kernel(const chap_chanmask_params& P) {

@@ -21,6 +21,9 @@
 #ifndef CHAP_CONV_MINWAVES
 #define CHAP_CONV_MINWAVES 1      // __launch_bounds__ 2nd argument (waves per SIMD) -- lab knob
 #endif
+#ifndef CHAP_ZW_INTERLEAVE
+#define CHAP_ZW_INTERLEAVE 1   // round-robin tile walk of the 3D brick kernels (see conv_fwd_kernel); 0 = contiguous runs (rounds 1-2)
+#endif
 #ifndef CHAP_ABLATE
 #define CHAP_ABLATE 0          // tools/lab/conv_lab.hip builds ablated variants; the library never does
 #endif
@@ -406,9 +409,19 @@ __device__ __forceinline__ void conv_fwd_kernel(const chap_conv_params& P) {
     const unsigned t_lo = per * (unsigned)xcd, t_hi = min(t_lo + per, (unsigned)ntiles);
     const unsigned range = t_hi > t_lo ? t_hi - t_lo : 0u;
     const unsigned tq = range / (unsigned)bpx, trem = range - tq * (unsigned)bpx;
-    const unsigned t_first = t_lo + (unsigned)bix * tq + min((unsigned)bix, trem);
-    const long my_tiles = (long)(tq + ((unsigned)bix < trem ? 1u : 0u));
+    // ILV (CHAP_ZW_INTERLEAVE, 3D bricks, round 3): the XCD's blocks take its tiles ROUND-ROBIN (block b: t_lo + b, t_lo + b + bpx, ...) instead of
+    // one contiguous run each, so that at any time they work on ~bpx CONSECUTIVE bricks -- a compact region whose halos overlap -- rather
+    // than on bpx runs spread over the whole 8 MB range of the XCD (more than its 4 MB L2).  Measured on the 16->16 layer at 112x112x80, N = 2
+    // (profiles/r03_pmc_traffic_walk_*.jsonl): L2-miss reads 106.6 -> 72.0 MB per launch (1.66x -> 1.12x the algorithmic 64.2 MB; reads +
+    // writes 1.33x -> 1.06x), kernel time unchanged (65.0 -> 65.6 us: the kernel is not traffic-bound), 3D step 14.97 -> 14.92 ms
+    constexpr bool ILV = (CHAP_ZW_INTERLEAVE != 0) && ZW;
+    const unsigned t_first = ILV ? t_lo + (unsigned)bix : t_lo + (unsigned)bix * tq + min((unsigned)bix, trem);
+    const long my_tiles = ILV ? (range > (unsigned)bix ? (long)((range - (unsigned)bix + (unsigned)bpx - 1u) / (unsigned)bpx) : 0l)
+                              : (long)(tq + ((unsigned)bix < trem ? 1u : 0u));
     const long nitems = my_tiles * nchunks;
+    // digits of the walk's step (1, or bpx when interleaved) in the mixed radix (z, x, y | x, y, z) of the tile coordinates
+    int stz = 0, stx = 0, sty = 0, stn = 0;
+    if (ILV) { unsigned q = (unsigned)bpx; stz = q % (unsigned)tiles_z; q /= (unsigned)tiles_z; stx = q % (unsigned)tiles_x; q /= (unsigned)tiles_x; sty = q % (unsigned)tiles_y; stn = q / (unsigned)tiles_y; }
 
     CHAP_STAMP_P(6);
     // ---- one-time per thread: unit descriptors, MFMA fragment offsets ----
@@ -621,10 +634,17 @@ __device__ __forceinline__ void conv_fwd_kernel(const chap_conv_params& P) {
             if (nchunk == nchunks) {
                 nchunk = 0;
                 int c = 1;
+                if (ILV) {
+                    ntz += stz; c = ntz >= tiles_z; ntz -= c ? tiles_z : 0;
+                    ntx += stx + c; c = ntx >= tiles_x; ntx -= c ? tiles_x : 0;
+                    nty += sty + c; c = nty >= tiles_y; nty -= c ? tiles_y : 0;
+                    nn += stn + c;
+                } else {
                 if (D3) { ntz += 1; c = ntz >= tiles_z; ntz -= c ? tiles_z : 0; }
                 ntx += c; c = ntx >= tiles_x; ntx -= c ? tiles_x : 0;
                 nty += c; c = nty >= tiles_y; nty -= c ? tiles_y : 0;
                 if (D3) nn += c; else { ntz += c; c = ntz >= tiles_z; ntz -= c ? tiles_z : 0; nn += c; }
+                }
             }
             halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW, ONE>(R, U, s0, s1, P.ID, P.IH, P.IW, nn, ntz * G::TD, nty * G::TH, ntx * G::TW, nchunk, lanesel);
             wstage_issue(nchunk);

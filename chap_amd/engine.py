@@ -102,6 +102,8 @@ def drive(gens, stream):
             if done != len(gens) or lanes:
                 raise RuntimeError("chap_amd: passes driven in lockstep made different numbers of steps")
             return results
+        if not lanes:
+            continue
         if len(lanes) == 1:
             lanes[0]()
         else:
@@ -166,6 +168,19 @@ class Executor:
             st = torch.cuda.Stream(device=parent.device)
             self._sides[key] = st
         return st
+
+    def _static_dims(self, D, H, W):
+        """value name -> (d, h, w) for an input of (D, H, W), without running anything (same rules as run_op)."""
+        dims, three = {self.prog.in_name: (D, H, W)}, self.prog.dims == 3
+        for op in self.prog.ops:
+            d, h, w = dims[op.srcs[0]] if op.srcs else (D, H, W)
+            if op.kind in ("pool", "down"):
+                dims[op.out] = (d // 2 if three else d, h // 2, w // 2)
+            elif op.kind in ("up", "deconv"):
+                dims[op.out] = (2 * d if three else d, 2 * h, 2 * w)
+            else:
+                dims[op.out] = (d, h, w)
+        return dims
 
     def _zipped(self):
         """The aligned schedule of the two decoder branches (zip_branches), built once per program."""
@@ -292,6 +307,19 @@ class Executor:
             for op_ in prog.ops:
                 if op_.drop:
                     drop_seed[id(op_)] = rng.next_seed()
+        # The element keep masks of the trunk (nn.Dropout of the five encoder ConvBlocks) depend on nothing but their seeds: they are
+        # generated up front, as the lanes of one step (same-sized ones share a grid), instead of one launch on the chain behind each conv
+        pre_keep = {}
+        if train:
+            elem = [op_ for op_ in prog.ops if op_.drop and op_.drop[2] == "elem" and op_.branch == 0 and op_.kind in ("c1", "conv")] if drop_masks is None else []
+            sdims = self._static_dims(D, H, W) if elem else None
+
+            def make_keep(op_):
+                keep = L.hold_empty((N,) + sdims[op_.out] + (op_.cout,), dtype=torch.uint8, device=dev)
+                ops.keep_mask(keep, drop_seed[id(op_)], op_.drop[1], seed_dev=rng.seed_dev)
+                pre_keep[id(op_)] = keep
+            yield [lambda op_=op_: make_keep(op_) for op_ in elem]        # (a step of every training-mode pass, possibly without lanes: passes driven together stay aligned)
+
         def run_op(op, V=vals, n=N):      # V / n: value table and batch size (the decoders of a perturbed pass see their own)
             nonlocal apos
             k = op.kind
@@ -392,6 +420,9 @@ class Executor:
                 if mode == "elem":
                     if drop_masks is not None:
                         keep = drop_masks.get(site)
+                    elif id(op) in pre_keep:
+                        keep = pre_keep[id(op)]
+                        assert keep.shape == out.shape
                     else:
                         keep = L.hold_empty(out.shape, dtype=torch.uint8, device=dev)
                         ops.keep_mask(keep, drop_seed[id(op)], p, seed_dev=rng.seed_dev)

@@ -187,6 +187,7 @@ class UNet(ChapNet):
         self._finish_init(build_program(class_num, [("decoder", True)]))
 
     def forward(self, x, with_feats=False, drop_masks=None, update_stats=True, grad_buffer=None):
-        if with_feats:
-            raise NotImplementedError("chap_amd: with_feats=True is not built yet")
+        if with_feats:      # unet.py:513-520 -> Decoder.forward(feature, True) (:187-190): (logits, the last decoder feature [N, 16, H, W])
+            out = self._run(x, drop_masks=drop_masks, update_stats=update_stats, want=["decoder.d4"], grad_buffer=grad_buffer)
+            return out[0], out[1]      # the feature is materialised NCHW fp32 and detached (like DualDecoder's with_feat features)
         return self._run(x, drop_masks=drop_masks, update_stats=update_stats, grad_buffer=grad_buffer)[0]

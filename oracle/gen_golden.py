@@ -181,6 +181,17 @@ def gen_2d(ref):
                         checks=_checks(list(md.state_dict().items())))
 
 
+def gen_unet_feats(ref):
+    """UNet.forward(x, with_feats=True) (unet.py:513-520): (logits, last decoder feature) of the imported reference, eval mode."""
+    mu = ref["UNet"](1, 4)
+    mu.load_state_dict(oinit.unet_2d_state(103), strict=True)
+    mu.eval()
+    x = torch.rand(2, 1, 32, 32, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        o, f = mu(x, True)
+    np.savez_compressed(os.path.join(OUT, "unet2d_feats_32.npz"), x=_np(x), state_seed=103, logits=_np(o), feat=_np(f))
+
+
 def gen_2d_variants(ref):
     """decoder_type 'plus' and 'same' (unet.py:270-275): eval and train-mode logits, input and picked weight gradients."""
     N, H, W = 2, 32, 32
@@ -462,7 +473,7 @@ def main():
     ref = import_reference()
     only = sys.argv[1:]                     # e.g. `gen_golden.py gen_3d_full`: (re)generate one fixture
     steps = [("gen_2d", lambda: gen_2d(ref)), ("gen_2d_variants", lambda: gen_2d_variants(ref)), ("gen_3d", lambda: gen_3d(ref)),
-             ("gen_3d_full", lambda: gen_3d_full(ref)), ("gen_filter_dropout", lambda: gen_filter_dropout(ref)),
+             ("gen_3d_full", lambda: gen_3d_full(ref)), ("gen_unet_feats", lambda: gen_unet_feats(ref)), ("gen_filter_dropout", lambda: gen_filter_dropout(ref)),
              ("gen_train_plumbing", gen_train_plumbing)]
     assert all(o in dict(steps) for o in only), only
     for name, fn in steps:

@@ -132,6 +132,18 @@ def test_dualdecoder_fullsize_and_unet(golden_dir):
     assert cosine(dx, g["eval_dx"]) > 0.99999
 
 
+def test_unet_with_feats(golden_dir):
+    """UNet.forward(x, with_feats=True) -> (logits, last decoder feature), unet.py:513-520, against the imported reference."""
+    g = _load(golden_dir, "unet2d_feats_32.npz")
+    u = net_factory("unet", 1, 4, DEV)
+    u.load_state_dict(oinit.unet_2d_state(int(g["state_seed"])), strict=True)
+    u.eval()
+    with torch.no_grad():
+        o, f = u(torch.from_numpy(g["x"]).to(DEV), True)
+    assert tuple(f.shape) == tuple(g["feat"].shape)
+    assert relerr(o, g["logits"]) < 1e-4 and relerr(f, g["feat"]) < 1e-4
+
+
 def test_train_mode_random_dropout_and_frozen():
     """in-kernel RNG dropout: runs, is reproducible for a fixed seed state, and the frozen()
     context yields dL/dx without touching parameter gradients."""

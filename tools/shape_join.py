@@ -9,7 +9,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from kname import short_name  # noqa: E402
 
 table, plan_f, trace_dir, out = sys.argv[1:5]
 rows = list(csv.DictReader(open(table)))
@@ -37,7 +41,7 @@ for i, pl in enumerate(plan):
         ds = ds[-pl["reps"] * (len(ds) // pl["reps"]):]
         us = sum(ds) / 1e3 / pl["reps"]
         tot_us += us
-        kern.append("%s = %.2f us" % (name.replace("void ", "").split("(")[0], us))
+        kern.append("%s = %.2f us" % (short_name(name), us))
     r = dict(by_key[(pl["op"], pl["shape"])])
     r["trace_us"] = round(tot_us, 2)
     r["kernels"] = " | ".join(kern)
