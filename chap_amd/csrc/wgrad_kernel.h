@@ -79,7 +79,16 @@ __device__ __forceinline__ void wgrad_kernel(const wgrad_args& A, int nb) {     
     const int split = blockIdx.x, chunk = blockIdx.y;
     const int tiles_x = (P.W + G::TW - 1) / G::TW, tiles_y = (P.H + G::TH - 1) / G::TH, tiles_z = (P.D + G::TD - 1) / G::TD;
     const long ntiles = (long)P.N * tiles_z * tiles_y * tiles_x;
-    const long my_tiles = split < ntiles ? (ntiles - split + nsplit - 1) / nsplit : 0;
+    // XCD-aware tile assignment (round 3): blocks (= splits) s and s + 8 run on the same XCD; that XCD owns a contiguous eighth of the tiles
+    // and its blocks take them round-robin, so that the tiles in flight on one XCD are neighbours whose halo rows hit in its L2.  With the
+    // plain `split + k * nsplit` of rounds 1-2 neighbouring tiles ran on different XCDs and every tile fetched its whole halo past the L2:
+    // 16->16 at 256x256, N = 12: 86.8 MB of L2-miss reads for 50.3 MB of operands (profiles/r03_pmc_traffic_kernels.json).
+    const int NG = nsplit < 8 ? nsplit : 8;                                // tile groups (one per XCD once there are >= 8 splits)
+    const int xcd = split % NG, sj = split / NG;
+    const int bpx = (nsplit + NG - 1 - xcd) / NG;                          // splits of this group
+    const long per = (ntiles + NG - 1) / NG;
+    const long t_lo = per * xcd, t_hi = t_lo + per < ntiles ? t_lo + per : ntiles;
+    const long my_tiles = (bpx > 0 && t_lo + sj < t_hi) ? (t_hi - t_lo - sj + bpx - 1) / bpx : 0;
 
     const src_scalars s0 = make_scalars(P.a[0]);
     const src_scalars s1 = make_scalars(P.na > 1 ? P.a[1] : P.a[0]);
@@ -214,8 +223,8 @@ __device__ __forceinline__ void wgrad_kernel(const wgrad_args& A, int nb) {     
             a_off[i] = ((dz * G::HH + rowl * ST + dy) * G::HW + (xb + qq) * ST + dx) * PS + kct * 16 + 4 * pp;
         }
     }
-    const long last_tile = split + (my_tiles > 0 ? my_tiles - 1 : 0) * nsplit;      // clamp target of the unconditional prefetch
-    auto tile_of = [&](long k) __attribute__((always_inline)) { const long t = split + k * nsplit; return t < last_tile ? t : last_tile; };
+    const long last_tile = t_lo + sj + (my_tiles > 0 ? my_tiles - 1 : 0) * bpx;     // clamp target of the unconditional prefetch
+    auto tile_of = [&](long k) __attribute__((always_inline)) { const long t = t_lo + sj + k * bpx; return t < last_tile ? t : last_tile; };
     if (my_tiles > 0) {
 #pragma unroll
         for (int d = 0; d < PD; ++d) issue(S[d], tile_of(d));
