@@ -20,7 +20,7 @@ from oracle import init as oinit
 from oracle import train_step as ots
 from tests.iteration_parity import assert_as_close_to_fp64_as_the_fp32_oracle, inject_2d, inject_3d, rms_over, three_way
 
-SEEDS = 4        # realisations per small case (data, dropout masks, VAT noise)
+SEEDS = int(os.environ.get("CHAP_CONDITIONING_SEEDS", "3"))        # realisations per small case (data, dropout masks, VAT noise); profiles/r03_iteration_parity.jsonl: 4
 
 
 # ------------------------------------------------------------------------------------------------ (1) small, ill-conditioned

@@ -11,6 +11,8 @@
   (d) a Dice gate for the bf16 throughput mode: N iterations in bf16 and in fp32 from one seed, Dice of the two
       checkpoints on held-out slices within a stated, measured bound (replaces the vacuous 2.0-on-probabilities bound).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -285,8 +287,8 @@ def _log_dice_gate(rec):
 
 # bound = 2 x the largest measured |mean Dice(bf16) - mean Dice(fp32)| (profiles/r03_dice_gate.jsonl).  The figure is a property of two
 # chaotic training trajectories, not of the arithmetic alone: it moved with every bit-level change of the step during round 3 (the
-# order in which two gradient contributions are added, grouped launches) -- 64 x 64: 0.0049, 0.0058; 256 x 256: 0.0184, 0.0420 -- while
-# two fp32 runs that differ only in the dropout / VAT-noise seed ended 0.0120, 0.0024 / 0.0156, 0.0103 apart.
+# order in which two gradient contributions are added, grouped launches) -- 64 x 64: 0.0049, 0.0058, 0.0002; 256 x 256: 0.0184, 0.0420, 0.0183 -- while
+# two fp32 runs that differ only in the dropout / VAT-noise seed ended 0.0120, 0.0024, 0.0072 / 0.0156, 0.0103, 0.0364 apart.
 DICE_GATE = {"64": dict(B=8, H=64, W=64, iters=1500, bound=0.012), "256": dict(B=24, H=256, W=256, iters=1500, bound=0.085)}
 
 
@@ -304,7 +306,8 @@ def test_bf16_training_dice_gate(size):
     c = DICE_GATE[size]
     d32 = _train_and_dice(torch.float32, 1337, c["B"], c["H"], c["W"], c["iters"])
     d16 = _train_and_dice(torch.bfloat16, 1337, c["B"], c["H"], c["W"], c["iters"])
-    d32b = _train_and_dice(torch.float32, 4711, c["B"], c["H"], c["W"], c["iters"])
+    # the seed-to-seed scale run: always at 64 x 64; at 256 x 256 (35 s more) only on request -- its figures are in profiles/r03_dice_gate.jsonl
+    d32b = _train_and_dice(torch.float32, 4711, c["B"], c["H"], c["W"], c["iters"]) if (size == "64" or os.environ.get("CHAP_DICE_SEED_RUN") == "1") else d32
     rec = {"size": "%dx%d" % (c["H"], c["W"]), "batch": c["B"], "iterations": c["iters"], "dice_fp32": d32.round(5).tolist(), "dice_bf16": d16.round(5).tolist(),
            "dice_fp32_other_seed": d32b.round(5).tolist(), "mean_fp32": round(float(d32.mean()), 5), "mean_bf16": round(float(d16.mean()), 5),
            "mean_fp32_other_seed": round(float(d32b.mean()), 5), "abs_delta_bf16_vs_fp32": round(abs(float(d32.mean() - d16.mean())), 5),
