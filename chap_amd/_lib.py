@@ -54,12 +54,17 @@ class ConvC1BwdParams(C.Structure):
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("dims", _i32), ("Cout", _i32), ("dtype", _i32)]
 
 
+class Bgrad(C.Structure):
+    _fields_ = [("dy", _vp), ("dy_ld", _i32), ("dy_coff", _i32), ("sums", _vp), ("mean", _vp), ("invstd", _vp), ("gamma", _vp),
+                ("count", _f32), ("gout", _vp)]
+
+
 class WgradParams(C.Structure):
     _fields_ = [("a", Src * 2), ("na", _i32), ("combine", _i32), ("b", Src),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("ID", _i32), ("IH", _i32), ("IW", _i32),
                 ("ksize", _i32), ("stride", _i32), ("dims", _i32),
                 ("dw", _vp), ("s_tap", _i64), ("s_kc", _i64), ("s_kn", _i64), ("kc_valid", _i32), ("kn_valid", _i32),
-                ("db", _vp), ("ws", _vp), ("ws_bytes", _sz), ("dtype", _i32)]
+                ("db", _vp), ("ws", _vp), ("ws_bytes", _sz), ("dtype", _i32), ("bgrad", Bgrad)]
 
 
 class BnFinalizeParams(C.Structure):

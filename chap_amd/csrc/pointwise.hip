@@ -5,6 +5,7 @@
 // the channel axis, wave64 shuffle reductions, one float atomic per block and channel.
 #include "common.h"
 #include "launch.h"
+#include "actbwd_math.h"
 
 // Index decoding uses 32-bit unsigned arithmetic (64-bit integer division costs ~100 VALU instructions on
 // gfx950 and turned these streaming kernels VALU-bound); entry points reject tensors with >= 2^32 elements.
@@ -569,29 +570,9 @@ __device__ __forceinline__ void act_bwd_dz(const chap_act_bwd_params& P, const f
             if (((w >> (8 * (j & 3))) & 0xff) == me) gsum[j] += v[j];
         }
     }
-    // a = keep*ks*cm*leaky(z), z = scale*raw+shift  ->  da/dz = keep*ks*cm*(z>0 ? 1 : slope)
-    if (s.act) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {          // packed fp32: z = raw*scale + shift (v_pk_fma_f32), dz = g * f (v_pk_mul_f32)
-            const f32x2 r2 = {raw[2 * j], raw[2 * j + 1]}, a2 = {sa[2 * j], sa[2 * j + 1]}, b2 = {sb[2 * j], sb[2 * j + 1]};
-            const f32x2 z = r2 * a2 + b2;
-            const f32x2 f = {z.x > 0.f ? 1.f : s.slope, z.y > 0.f ? 1.f : s.slope};
-            const f32x2 g2 = {gsum[2 * j], gsum[2 * j + 1]};
-            const f32x2 d = g2 * f;
-            dz[2 * j] = d.x; dz[2 * j + 1] = d.y;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dz[j] = gsum[j];
-    }
-    if (s.keep) {
-        const uint2 m = *(const uint2*)(s.keep + pix * C + c8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const uint32_t w = j < 4 ? m.x : m.y;
-            dz[j] = ((w >> (8 * (j & 3))) & 0xff) ? dz[j] * s.keep_scale : 0.f;
-        }
-    }
+    // a = keep*ks*cm*leaky(z), z = scale*raw+shift  ->  da/dz = keep*ks*cm*(z>0 ? 1 : slope)      (actbwd_math.h)
+    actbwd_deriv8(raw, gsum, sa, sb, s.act != 0, s.slope, dz);
+    if (s.keep) actbwd_keep8(dz, *(const uint2*)(s.keep + pix * C + c8), s.keep_scale);
     if (s.chan_mul) {
         float cm[8];
         ld8(s.chan_mul + (long)n * C + c8, cm);
@@ -670,14 +651,8 @@ __device__ __forceinline__ void act_bwd_kernel(const act_bwd_args& A) {
             ld8(P.gamma + c8, gm);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { a0[j] = red[c8 + j]; a1[j] = red[C + c8 + j]; }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { k0[j] = gm[j] * istd[j]; k1[j] = a0[j] / P.count; k2[j] = a1[j] / P.count; }
-            // g = k0*(dz - k1 - xhat*k2), xhat = raw*istd - mean*istd  ==  dz*k0 + raw*cB + cC  (two FMAs per element)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                cB[j] = -istd[j] * k0[j] * k2[j];
-                cC[j] = -k0[j] * k1[j] + mean[j] * istd[j] * k0[j] * k2[j];
-            }
+            // g = k0*(dz - k1 - xhat*k2), xhat = raw*istd - mean*istd  ==  dz*k0 + raw*cB + cC  (two FMAs per element; actbwd_math.h)
+            actbwd_consts8(a0, a1, gm, mean, istd, P.count, k0, cB, cC);
         } else if (P.r.scale) {                        // fixed affine (eval-mode BN): dz/draw = scale
             ld8(P.r.scale + c8, k0);
         }
@@ -706,13 +681,7 @@ __device__ __forceinline__ void act_bwd_kernel(const act_bwd_args& A) {
                 }
             } else {
                 float o[8];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x2 d = {dz[2 * j], dz[2 * j + 1]}, r2 = {raw[2 * j], raw[2 * j + 1]};
-                    const f32x2 A = {k0[2 * j], k0[2 * j + 1]}, B = {cB[2 * j], cB[2 * j + 1]}, Cc = {cC[2 * j], cC[2 * j + 1]};
-                    const f32x2 r = d * A + (r2 * B + Cc);         // bn != 1: cB = cC = 0 -> dz*k0
-                    o[2 * j] = r.x; o[2 * j + 1] = r.y;
-                }
+                actbwd_apply8(dz, raw, k0, cB, cC, o);         // bn != 1: cB = cC = 0 -> dz*k0
                 st8((T*)P.gout + pix * C + c8, o);
             }
         }

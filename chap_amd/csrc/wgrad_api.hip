@@ -140,6 +140,11 @@ extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     CHAP_CHECK_ARG(p->ID == (p->stride == 1 ? p->D : p->D * sd) && p->IH == p->H * p->stride && p->IW == p->W * p->stride,
                    "chap_wgrad: A dims (%d,%d,%d) do not match grid (%d,%d,%d) stride %d", p->ID, p->IH, p->IW, p->D, p->H, p->W, p->stride);
     if (p->dims == 3 && (p->a[0].keep || (p->na > 1 && p->a[1].keep))) { chap_set_error("chap_wgrad: element keep masks on the A operand are built for 2D only"); return CHAP_EUNSUPPORTED; }
+    if (p->bgrad.dy) {         // B computed on the fly (chap_bgrad_t)
+        CHAP_CHECK_ARG(p->bgrad.sums && p->bgrad.mean && p->bgrad.invstd && p->bgrad.gamma && p->bgrad.count > 0, "chap_wgrad: bgrad needs sums, mean, invstd, gamma, count");
+        CHAP_CHECK_ARG(p->bgrad.dy_ld % 8 == 0 && p->bgrad.dy_coff % 8 == 0 && p->bgrad.dy_ld >= p->bgrad.dy_coff + p->b.C, "chap_wgrad: bgrad.dy ld=%d coff=%d", p->bgrad.dy_ld, p->bgrad.dy_coff);
+        CHAP_CHECK_ARG(p->b.scale && p->b.C % 8 == 0, "chap_wgrad: bgrad needs b = the raw conv output with its forward BatchNorm affine");
+    }
     float* ws = (float*)p->ws;
     float* ws_db = p->db ? ws + (size_t)q.nsplit * (q.slab / sizeof(float)) : nullptr;
     hipStream_t s = (hipStream_t)stream;

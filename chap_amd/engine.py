@@ -114,6 +114,16 @@ def drive(gens, stream):
                     f()
 
 
+def lazy_gradient_enabled():
+    """CHAP_LAZY_GRAD=1 (lab / A-B switch, default 0): fold the apply phase of the BatchNorm / activation backward into the weight
+    gradient wherever a layer has one incoming gradient (chap_bgrad_t).  Bit-identical to the separate launch
+    (tests/test_kernels_bwd_gpu.py::test_lazy_gradient_in_wgrad_equals_the_apply_launch) and SLOWER on the whole iteration (round 3, two
+    on-box A/B pairs: 2D 6.76-6.80 -> 6.81-6.85 ms, 3D 14.93 -> 15.29-15.37 ms): the weight gradient -- a per-tile round-trip chain --
+    stages a second tensor, does the backward math in its commit phase and writes g, which costs more than the apply launch it replaces."""
+    import os
+    return os.environ.get("CHAP_LAZY_GRAD", "0") == "1"
+
+
 def grouping_mode():
     """CHAP_GROUP (lab / A-B switch): 0 = never group (round 2: decoders back to back where a pass cannot fork), 1 (default) = group the
     two decoders' same-shaped layers in the passes that cannot fork a second stream, 2 = group in every pass (no second stream)."""
@@ -555,6 +565,7 @@ class Executor:
                     contrib.setdefault(op.srcs[0], []).append((o, 0, okey[id(op)]))
                 return
             # ---- gradient w.r.t. the raw output of this conv
+            bgrad, v = None, None
             if op.head:
                 dl = head_g.get(op.out)
                 if dl is None:
@@ -572,6 +583,7 @@ class Executor:
                 v = V[op.out]
                 gd = S.dims[op.out]
                 kn_valid = 0
+                bgrad = None
                 plain = (v.scale is None and not v.act and v.keep is None and v.chan_mul is None)
                 if plain and pl is None and len(c) == 1:
                     g = Lazy(c[0][0], C=v.C, coff=c[0][1])
@@ -593,26 +605,33 @@ class Executor:
                             kw.update(dgamma=gr[op.bn + ".weight"], dbeta=gr[op.bn + ".bias"])
                     if op.bn:
                         kw["sums"] = take_sums(v.C)
-                    ops.act_bwd(v, c or [], gout, g_pool=pl[0] if pl else None, pool_idx=pl[1] if pl else None, **kw)
+                    # "lazy gradient" (round 3): with ONE incoming gradient under a training-mode BatchNorm the apply phase runs inside the
+                    # weight gradient's B staging (chap_bgrad_t) -- one launch and one pass over dy and x less; the weight gradient stores g
+                    # for the input-gradient conv below.  Not for the transposed conv (there g is the A operand) or the fp32 first layer.
+                    fuse = bool(lazy_gradient_enabled() and need_wgrad and op.bn and S.train and c and len(c) == 1 and pl is None and
+                                (k in ("conv", "down") or (k == "c1" and S.xpad is not None)))
+                    ops.act_bwd(v, c or [], gout, g_pool=pl[0] if pl else None, pool_idx=pl[1] if pl else None, apply=not fuse, **kw)
                     g = Lazy(gout)
+                    if fuse:
+                        bgrad = dict(dy=c[0], sums=kw["sums"], mean=kw["mean"], invstd=kw["invstd"], gamma=kw["gamma"], count=kw["count"], gout=gout)
             # ---- this conv's own backward
             if k == "c1":
                 D, H, W = S.dims[op.out]
                 gt = g.raw if (g.coff == 0 and g.C == g.ld) else None
                 assert gt is not None
+                if need_wgrad:      # (first: with the lazy gradient it is the weight gradient that writes g)
+                    if S.xpad is not None:
+                        taps = 3 ** dims
+                        ops.wgrad([Lazy(S.xpad)], v if bgrad else g, gr[op.w], (1, taps, taps), grid=(n, D, H, W), in_dims=(D, H, W),
+                                  ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=1, bgrad=bgrad)
+                    else:
+                        ops.conv_c1_bwd(gt, sd[op.w], S.x.view(n, D, H, W), dims=dims, dx=None,
+                                        dw=gr[op.w], db=gr[op.b] if op.b else None)
                 if need_dx:
                     dx = L.hold_empty_like(S.x)      # [n, 1, *spatial] fp32 == planar output with one channel
                     wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
                     ops.conv_fwd([g], wp, None, 1, dx, grid=(n, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=dims,
                                  out_planar=True, out_f32=True)
-                if need_wgrad:
-                    if S.xpad is not None:
-                        taps = 3 ** dims
-                        ops.wgrad([Lazy(S.xpad)], g, gr[op.w], (1, taps, taps), grid=(n, D, H, W), in_dims=(D, H, W),
-                                  ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=1)
-                    else:
-                        ops.conv_c1_bwd(gt, sd[op.w], S.x.view(n, D, H, W), dims=dims, dx=None,
-                                        dw=gr[op.w], db=gr[op.b] if op.b else None)
                 return
             srcs = [V[s] for s in op.srcs]
             sd_, sh_, sw_ = S.dims[op.srcs[0]]
@@ -620,8 +639,8 @@ class Executor:
             if k == "conv":
                 taps = op.ksize ** dims
                 if need_wgrad:
-                    ops.wgrad(srcs, g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
-                              ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid)
+                    ops.wgrad(srcs, v if bgrad else g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
+                              ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid, bgrad=bgrad)
                 wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
@@ -629,8 +648,8 @@ class Executor:
             elif k == "down":
                 gdd = S.dims[op.out]
                 if need_wgrad:
-                    ops.wgrad(srcs, g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
-                              ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None)
+                    ops.wgrad(srcs, v if bgrad else g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
+                              ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, bgrad=bgrad)
                 wp = self._pack(op, L.PACK_DOWN_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, nsub * ctot, dsrc, grid=(n,) + gdd, in_dims=gdd, ksize=1, stride=1, dims=dims,

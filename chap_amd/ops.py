@@ -139,8 +139,16 @@ def conv_c1_bwd(g, w, x, *, dims, dx=None, dw=None, db=None):
     L.call("chap_conv_c1_bwd", p, _stream())
 
 
-def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine=0, db=None, kc_valid=0, kn_valid=0):
+def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine=0, db=None, kc_valid=0, kn_valid=0, bgrad=None):
+    """bgrad (chap_bgrad_t, "lazy gradient"): dict(dy=(tensor, coff), sums=, mean=, invstd=, gamma=, count=, gout=) -- `b` is then the RAW conv
+    output with its forward transform and the B operand g = BatchNorm / activation backward of dy is computed while it is staged (and stored
+    to gout for the input-gradient conv): chap_act_bwd_apply folded into this launch."""
     p = L.WgradParams()
+    if bgrad is not None:
+        dy, coff = bgrad["dy"]
+        p.bgrad.dy, p.bgrad.dy_ld, p.bgrad.dy_coff = dy.data_ptr(), dy.shape[-1], coff
+        p.bgrad.sums, p.bgrad.mean, p.bgrad.invstd, p.bgrad.gamma = bgrad["sums"].data_ptr(), bgrad["mean"].data_ptr(), bgrad["invstd"].data_ptr(), bgrad["gamma"].data_ptr()
+        p.bgrad.count, p.bgrad.gout = float(bgrad["count"]), _p(bgrad.get("gout"))
     for i, s in enumerate(a_srcs):
         s.fill(p.a[i])
     p.na, p.combine = len(a_srcs), combine
@@ -222,7 +230,7 @@ def _act_bwd_params(lazy, grads, g_pool, pool_idx, mean, invstd, gamma, sums, go
 
 
 def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=None, gamma=None,
-            dgamma=None, dbeta=None, count=1.0, bn_mode=None, sums=None):
+            dgamma=None, dbeta=None, count=1.0, bn_mode=None, sums=None, apply=True):
     """grads: list of (tensor, channel offset).
     bn_mode 1 (default when mean is given): training-mode BN backward fused in;
     bn_mode 2: fixed affine (eval-mode BN), dgamma/dbeta from the same reduction when requested."""
@@ -235,7 +243,9 @@ def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=
     p.bn = bn_mode
     if need_reduce:
         L.call("chap_act_bwd_reduce", p, _stream())
-    L.call("chap_act_bwd_apply", p, _stream())
+    if apply:               # apply=False: the caller folds the apply phase into the weight gradient (wgrad(bgrad=...)); `sums` row 0 holds the totals
+        L.call("chap_act_bwd_apply", p, _stream())
+    return sums
 
 
 def act_bwd_sums_size(c):

@@ -180,6 +180,20 @@ int    chap_conv_c1_bwd(const chap_conv_c1_bwd_params* p, void* stream);
  * Partials are written per pixel-split to `ws` and reduced deterministically (no atomics) into
  * dw (+=) using element strides so the result lands in checkpoint layout.  Also db (+= sum_p B)
  * when requested (valid when B is the output gradient). */
+/* Optional "lazy gradient" (round 3): B is not read but COMPUTED while it is staged -- the apply phase of chap_act_bwd_* folded into the
+ * weight gradient.  With dy != NULL the operand b describes the RAW conv output x and its forward transform (what chap_act_bwd_params.r
+ * describes), and B[p][c] = g = gamma*invstd*(dz - S0/cnt - xhat*S1/cnt) with dz = dy * da/dz exactly as chap_act_bwd_apply computes it
+ * (same fp32 operations, same bf16 rounding: bit-identical), from the totals row 0 of `sums` that chap_act_bwd_reduce left.  The blocks of the
+ * first A-chunk also store g to `gout` ([pixels][Cb], dtype) for the input-gradient convolution that follows.  One incoming gradient, no pooled
+ * gradient; training-mode BatchNorm only. */
+typedef struct {
+    const void*  dy;  int32_t dy_ld, dy_coff;   /* incoming gradient w.r.t. the activated value (dtype), on B's grid; NULL = feature off */
+    const float* sums;                           /* row 0 of the BN-backward workspace: S0[C] | S1[C]                                     */
+    const float* mean; const float* invstd; const float* gamma;
+    float        count;
+    void*        gout;                           /* g is also written here, or NULL                                                       */
+} chap_bgrad_t;
+
 typedef struct {
     chap_src_t  a[2];          /* strided operand, up to two concatenated/added sources           */
     int32_t     na;  int32_t combine;
@@ -193,6 +207,7 @@ typedef struct {
     float*      db;            /* [Cb] += or NULL                                                 */
     void*       ws;  size_t ws_bytes;
     int32_t     dtype;
+    chap_bgrad_t bgrad;        /* B computed on the fly from (dy, b = raw x): see chap_bgrad_t; bgrad.dy == NULL: B is read from b */
 } chap_wgrad_params;
 size_t chap_wgrad_ws(const chap_wgrad_params* p);
 int    chap_wgrad(const chap_wgrad_params* p, void* stream);

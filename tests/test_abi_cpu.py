@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_struct_sizes_match_header(tmp_path):
     """compile a tiny C program that prints sizeof() of every params struct and compare with ctypes."""
     from chap_amd import _lib
-    pairs = {"chap_src_t": _lib.Src, "chap_conv_params": _lib.ConvParams, "chap_pack_params": _lib.PackParams,
+    pairs = {"chap_src_t": _lib.Src, "chap_bgrad_t": _lib.Bgrad, "chap_conv_params": _lib.ConvParams, "chap_pack_params": _lib.PackParams,
              "chap_conv_c1_params": _lib.ConvC1Params, "chap_conv_c1_bwd_params": _lib.ConvC1BwdParams,
              "chap_wgrad_params": _lib.WgradParams, "chap_bn_finalize_params": _lib.BnFinalizeParams,
              "chap_bn_eval_params": _lib.BnEvalParams, "chap_act_bwd_params": _lib.ActBwdParams,
