@@ -594,12 +594,12 @@ __device__ __forceinline__ void act_bwd_kernel(const act_bwd_args& A) {
     const long npix = (long)P.N * P.D * P.H * P.W;
     const int c8 = (threadIdx.x % C8) * 8;
     const int prow = threadIdx.x / C8, PPB = 256 / C8;      // C8 in {2,4,8,...,32} divides 256
-    float s0[8], s1[8], mean[8], istd[8], k0[8], k1[8], k2[8], sa[8], sb[8], cB[8], cC[8], cM[8];
+    float s0[8], s1[8], mean[8], istd[8], k0[8], sa[8], sb[8], cB[8], cC[8], cM[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; sa[j] = 1.f; sb[j] = 0.f; }
     if (P.r.scale) { ld8(P.r.scale + c8, sa); ld8(P.r.shift + c8, sb); }      // per-channel constants: loaded once
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { k0[j] = 1.f; k1[j] = 0.f; k2[j] = 0.f; mean[j] = 0.f; istd[j] = 1.f; }
+    for (int j = 0; j < 8; ++j) { k0[j] = 1.f; mean[j] = 0.f; istd[j] = 1.f; }
     if (P.bn) { ld8(P.mean + c8, mean); ld8(P.invstd + c8, istd); }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { cB[j] = 0.f; cC[j] = 0.f; cM[j] = -mean[j] * istd[j]; }      // xhat = raw*istd + cM

@@ -214,3 +214,21 @@ def test_train_loop_reiterates_a_finite_loader_until_max_iterations(tmp_path, mo
     with pytest.raises(RuntimeError, match="yielded no batch"):
         T.train(dict(trainloader=iter(loader), val_volumes=[], max_iterations=7, val_interval=1000, use_graph=False, image_size=[4, 4]), str(tmp_path / "run2"))
     assert seen == [0, 1, 2]
+
+
+def test_group_region_state_machine_without_a_gpu():
+    """chap_group_begin / _next_lane / _end (ABI 5) keep host-side state only until something is launched: an empty region is legal and
+    issues nothing; regions do not nest; _next_lane / _end outside a region are errors (negative code + message)."""
+    from chap_amd import _lib
+    lib = _lib.lib()
+    lib.chap_group_begin.argtypes = [ctypes.c_void_p]
+    assert lib.chap_group_begin(None) == 0
+    assert lib.chap_group_begin(None) < 0 and b"nest" in lib.chap_last_error()
+    assert lib.chap_group_next_lane() == 0
+    assert lib.chap_group_end() == 0                      # nothing recorded: zero grids
+    assert lib.chap_group_end() < 0 and b"not recording" in lib.chap_last_error()
+    assert lib.chap_group_next_lane() < 0
+    with _lib.group(None) as g:                           # the Python wrapper: same calls, held tensors dropped at exit
+        g.next_lane()
+        assert _lib.group.held == []
+    assert _lib.group.held is None

@@ -36,7 +36,10 @@ def test_small_2d_iteration_is_as_close_to_fp64_as_the_fp32_oracle(variant):
         vol, lab = ots.synthetic_batch(1441 + s, lbs, U, H, W)
         runs.append(three_way("2d_64_%s_s%d" % (variant, s), 2, state, vol, lab, (9 + s, 4 + 2 * s), 4500, args, inject_2d(U, lbs // 2 + U // 2, H, W, K, seed=50 * s)))
         assert runs[-1]["hip_o32"]["loss"] < 2e-4           # absolute: the losses are well conditioned whatever the variant
-    assert_as_close_to_fp64_as_the_fp32_oracle(rms_over(runs))
+    # floor of the extreme-value statistic cos_min: what the fp32 ORACLE itself reaches against fp64 in the ill-conditioned variants (K = 2:
+    # 0.025, sign: 0.007), 5e-3 for the well-conditioned ones (measured HIP 0.0007 .. 0.0020 there)
+    floor = 2.5e-2 if ("k2" in variant or "sign" in variant) else 5e-3
+    assert_as_close_to_fp64_as_the_fp32_oracle(rms_over(runs), floors=dict(one_minus_cos=floor))
 
 
 @pytest.mark.parametrize("K", [1, 2])
@@ -50,7 +53,7 @@ def test_small_3d_iteration_is_as_close_to_fp64_as_the_fp32_oracle(K):
         vol, lab = ots.synthetic_batch_3d(1338 + s, lbs, U, *sp)
         runs.append(three_way("3d_16x32x16_k%d_s%d" % (K, s), 3, state, vol, lab, (2, 5 - s, 3), 4500, args, inject_3d(U, lbs // 2 + U // 2, sp, K, seed=50 * s)))
         assert runs[-1]["hip_o32"]["loss"] < 5e-4
-    assert_as_close_to_fp64_as_the_fp32_oracle(rms_over(runs))
+    assert_as_close_to_fp64_as_the_fp32_oracle(rms_over(runs), floors=dict(one_minus_cos=6.5e-2))      # the oracle's own worst 3D case (K = 2)
 
 
 # ------------------------------------------------------------------------------------------------ (2) the BASELINE sizes

@@ -437,3 +437,49 @@ def test_conv3x3_k_parallel(dims, shape, c0, c1, cout, monkeypatch):
     rc = refc - cshift.view(1, -1, 1, 1, 1)
     assert relerr(s1[0], rc.sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
     assert relerr(s1[1], (rc * rc).sum((0, 2, 3, 4))) < 1e-3 + TOL[dtype]
+
+
+def test_group_region_contract():
+    """Grouped launches at the C-ABI level: two same-shaped convs + finalizes recorded in two lanes are issued as 2 grids (instead of 4) and give
+    the bits of the separate launches; lanes of different shapes are issued one after the other; an entry point whose kernel is launched
+    directly (chap_sgd_step) is refused inside a region."""
+    from chap_amd import _lib as L
+    from chap_amd import ops
+    g = torch.Generator().manual_seed(9)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def layer(C, H):
+        x = torch.randn(2, 1, H, H, C, generator=g).to(DEV).to(torch.bfloat16)
+        w = (torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(DEV)
+        return x, ops.pack_weights(w, L.PACK_CONV_FWD, torch.bfloat16, C, C, 9), torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+
+    def run(x, wp, gam, bet):
+        C, H = x.shape[-1], x.shape[2]
+        out, stats = torch.empty_like(x), ops.stats_buffer(C, DEV)
+        scale, shift = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        ops.conv_fwd([ops.Lazy(x)], wp, None, C, out, grid=(2, 1, H, H), in_dims=(1, H, H), ksize=3, stride=1, dims=2, stats=stats)
+        ops.bn_finalize(stats, gam, bet, None, None, None, 2 * H * H, 1e-5, 0.0, scale, shift)
+        return out, scale, shift
+
+    a, b, c = layer(16, 48), layer(16, 48), layer(32, 24)
+    ref = [run(*a), run(*b), run(*c)]
+    n0 = L.group.launched
+    with L.group(st) as region:
+        got_a = run(*a)
+        region.next_lane()
+        got_b = run(*b)
+    assert L.group.launched - n0 == 2                       # conv x 2 lanes, finalize x 2 lanes
+    n0 = L.group.launched
+    with L.group(st) as region:
+        got_a2 = run(*a)
+        region.next_lane()
+        got_c = run(*c)
+    assert L.group.launched - n0 == 4                       # different shapes: nothing to merge
+    torch.cuda.synchronize()
+    for r, q in ((ref[0], got_a), (ref[1], got_b), (ref[0], got_a2), (ref[2], got_c)):
+        assert all(torch.equal(u, v) for u, v in zip(r, q))
+    p, m, lr = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV), torch.full((1,), 0.1, device=DEV)
+    with pytest.raises(L.ChapError, match="chap_group"):
+        with L.group(st):
+            ops.sgd_step(p, torch.ones(64, device=DEV), m, lr, 0.9, 0.0)
+    assert L.group.held is None                             # the region was left
