@@ -59,12 +59,18 @@ class Bgrad(C.Structure):
                 ("count", _f32), ("gout", _vp)]
 
 
+class WgradReduceEntry(C.Structure):
+    _fields_ = [("ws", _vp), ("ws_db", _vp), ("dw", _vp), ("db", _vp), ("s_tap", _i64), ("s_kc", _i64), ("s_kn", _i64),
+                ("nsplit", _i32), ("taps", _i32), ("Ca", _i32), ("Cb", _i32), ("kc_valid", _i32), ("kn_valid", _i32),
+                ("nb_dw", _i32), ("nblocks", _i32), ("e4", _i32)]
+
+
 class WgradParams(C.Structure):
     _fields_ = [("a", Src * 2), ("na", _i32), ("combine", _i32), ("b", Src),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("ID", _i32), ("IH", _i32), ("IW", _i32),
                 ("ksize", _i32), ("stride", _i32), ("dims", _i32),
                 ("dw", _vp), ("s_tap", _i64), ("s_kc", _i64), ("s_kn", _i64), ("kc_valid", _i32), ("kn_valid", _i32),
-                ("db", _vp), ("ws", _vp), ("ws_bytes", _sz), ("dtype", _i32), ("bgrad", Bgrad)]
+                ("db", _vp), ("ws", _vp), ("ws_bytes", _sz), ("dtype", _i32), ("bgrad", Bgrad), ("deferred", C.POINTER(WgradReduceEntry))]
 
 
 class BnFinalizeParams(C.Structure):
@@ -286,6 +292,20 @@ def pack_describe(params):
     if rc != 0:
         raise ChapError("chap_pack_describe failed (%d): %s" % (rc, L.chap_last_error().decode()))
     return e
+
+
+def wgrad_reduce_multi(entries, stream):
+    """chap_wgrad_reduce_multi: the slab reductions of the weight gradients recorded in `entries` (WgradReduceEntry objects that
+    chap_wgrad filled), up to 16 layers per launch."""
+    if not entries:
+        return
+    L = lib()
+    L.chap_wgrad_reduce_multi.restype = C.c_int
+    L.chap_wgrad_reduce_multi.argtypes = [C.POINTER(WgradReduceEntry), _i32, _vp]
+    arr = (WgradReduceEntry * len(entries))(*entries)
+    rc = L.chap_wgrad_reduce_multi(arr, len(entries), _vp(stream))
+    if rc != 0:
+        raise ChapError("chap_wgrad_reduce_multi failed (%d): %s" % (rc, L.chap_last_error().decode()))
 
 
 def pack_multi(entries_dev_ptr, n, max_total, stream):

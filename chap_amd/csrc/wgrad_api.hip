@@ -88,7 +88,7 @@ extern "C" size_t chap_wgrad_ws(const chap_wgrad_params* p) {
 // Blocks [0, nb_dw) reduce dW, blocks [nb_dw, ...) reduce the bias-gradient partials the same way.
 struct wgrad_reduce_args { const float* ws; const float* ws_db; int nsplit, taps, Ca, Cb; float* dw; long s_tap, s_kc, s_kn; int kc_valid, kn_valid; float* db; int nb_dw; };
 template <int E4>
-__device__ __forceinline__ void wgrad_reduce_kernel(const wgrad_reduce_args& A) {
+__device__ __forceinline__ void wgrad_reduce_body(const wgrad_reduce_args& A, const int bid) {
     const float* __restrict__ ws = A.ws; const float* __restrict__ ws_db = A.ws_db;
     const int nsplit = A.nsplit, taps = A.taps, Ca = A.Ca, Cb = A.Cb, kc_valid = A.kc_valid, kn_valid = A.kn_valid, nb_dw = A.nb_dw;
     float* dw = A.dw; float* db = A.db;
@@ -96,9 +96,9 @@ __device__ __forceinline__ void wgrad_reduce_kernel(const wgrad_reduce_args& A) 
     constexpr int G = 256 / E4;
     __shared__ float4 red[G][E4];
     const int col = threadIdx.x % E4, g = threadIdx.x / E4;
-    const bool is_db = (int)blockIdx.x >= nb_dw;                 // bias gradient: Cb values x nsplit partials, same scheme
+    const bool is_db = bid >= nb_dw;                             // bias gradient: Cb values x nsplit partials, same scheme
     const long total = is_db ? (long)Cb : (long)taps * Ca * Cb;
-    const long i = ((long)(is_db ? blockIdx.x - nb_dw : blockIdx.x) * E4 + col) * 4;
+    const long i = ((long)(is_db ? bid - nb_dw : bid) * E4 + col) * 4;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
     if (i < total) {
         const float* src = (is_db ? ws_db : ws) + i;
@@ -130,6 +130,43 @@ __device__ __forceinline__ void wgrad_reduce_kernel(const wgrad_reduce_args& A) 
     }
 }
 
+template <int E4>
+__device__ __forceinline__ void wgrad_reduce_kernel(const wgrad_reduce_args& A) { wgrad_reduce_body<E4>(A, (int)blockIdx.x); }
+
+// the reductions of up to WG_MULTI layers in one grid: block -> (entry, block of that entry's own reduction grid)
+constexpr int WG_MULTI = 16;
+struct wgrad_reduce_multi_args { wgrad_reduce_args e[WG_MULTI]; int e4[WG_MULTI]; int first[WG_MULTI + 1]; int n; };
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const wgrad_reduce_multi_args M) {
+    int j = 0;
+    while (j + 1 < M.n && (int)blockIdx.x >= M.first[j + 1]) ++j;          // uniform scan over <= 16 offsets
+    const int bid = (int)blockIdx.x - M.first[j];
+    if (M.e4[j] == 8) wgrad_reduce_body<8>(M.e[j], bid);
+    else wgrad_reduce_body<64>(M.e[j], bid);
+}
+
+extern "C" int chap_wgrad_reduce_multi(const chap_wgrad_reduce_entry* E, int32_t n, void* stream) {
+    CHAP_CHECK_ARG(E && n > 0, "chap_wgrad_reduce_multi: bad argument");
+    CHAP_NOT_IN_GROUP("chap_wgrad_reduce_multi");
+    for (int i0 = 0; i0 < n; i0 += WG_MULTI) {
+        wgrad_reduce_multi_args M;
+        M.n = n - i0 < WG_MULTI ? n - i0 : WG_MULTI;
+        int blocks = 0;
+        for (int k = 0; k < M.n; ++k) {
+            const chap_wgrad_reduce_entry& e = E[i0 + k];
+            CHAP_CHECK_ARG(e.ws && e.dw && e.nsplit > 0 && e.nblocks > 0 && (e.e4 == 8 || e.e4 == 64), "chap_wgrad_reduce_multi: entry %d was not filled by chap_wgrad", i0 + k);
+            M.e[k] = wgrad_reduce_args{e.ws, e.ws_db, e.nsplit, e.taps, e.Ca, e.Cb, e.dw, (long)e.s_tap, (long)e.s_kc, (long)e.s_kn, e.kc_valid, e.kn_valid, e.db, e.nb_dw};
+            M.e4[k] = e.e4;
+            M.first[k] = blocks;
+            blocks += e.nblocks;
+        }
+        for (int k = M.n; k < WG_MULTI; ++k) { M.e[k] = M.e[0]; M.e4[k] = M.e4[0]; }
+        for (int k = M.n; k <= WG_MULTI; ++k) M.first[k] = blocks;
+        hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M);
+        CHAP_LAUNCH_CHECK("chap_wgrad_reduce_multi");
+    }
+    return CHAP_OK;
+}
+
 extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->dw && p->ws && p->b.ptr && p->a[0].ptr, "chap_wgrad: null argument");
     wg_plan q;
@@ -155,12 +192,16 @@ extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     const long total = (long)q.taps * q.Ca * q.Cb;
     const int kcv = p->kc_valid > 0 ? p->kc_valid : q.Ca, knv = p->kn_valid > 0 ? p->kn_valid : q.Cb;
     wgrad_reduce_args ra = {(const float*)ws, (const float*)ws_db, q.nsplit, q.taps, q.Ca, q.Cb, p->dw, (long)p->s_tap, (long)p->s_kc, (long)p->s_kn, kcv, knv, p->db, 0};
-    if (q.nsplit >= 64) {      // (8 elements per block / 128 slab groups for the 768-split layers measured 25 us against 7 us: too few loads in flight per thread)
-        const int nb_db = p->db ? cdiv(q.Cb, 32) : 0;
-        ra.nb_dw = cdiv(total, 32);
-        return chap_launch<wgrad_reduce_args, wgrad_reduce_kernel<8>, 256>(dim3(ra.nb_dw + nb_db), dim3(256), 0, s, ra, "chap_wgrad(reduce)");
+    const int e4 = q.nsplit >= 64 ? 8 : 64;      // (8 elements per block / 128 slab groups for the 768-split layers measured 25 us against 7 us: too few loads in flight per thread)
+    const int nb_db = p->db ? cdiv(q.Cb, 4 * e4) : 0;
+    ra.nb_dw = cdiv(total, 4 * e4);
+    if (p->deferred) {         // the caller reduces the slabs of many layers at once (chap_wgrad_reduce_multi)
+        chap_wgrad_reduce_entry* d = p->deferred;
+        d->ws = ws; d->ws_db = ws_db; d->dw = p->dw; d->db = p->db; d->s_tap = p->s_tap; d->s_kc = p->s_kc; d->s_kn = p->s_kn;
+        d->nsplit = q.nsplit; d->taps = q.taps; d->Ca = q.Ca; d->Cb = q.Cb; d->kc_valid = kcv; d->kn_valid = knv;
+        d->nb_dw = ra.nb_dw; d->nblocks = ra.nb_dw + nb_db; d->e4 = e4;
+        return CHAP_OK;
     }
-    const int nb_db = p->db ? cdiv(q.Cb, 256) : 0;
-    ra.nb_dw = cdiv(total, 256);
+    if (e4 == 8) return chap_launch<wgrad_reduce_args, wgrad_reduce_kernel<8>, 256>(dim3(ra.nb_dw + nb_db), dim3(256), 0, s, ra, "chap_wgrad(reduce)");
     return chap_launch<wgrad_reduce_args, wgrad_reduce_kernel<64>, 256>(dim3(ra.nb_dw + nb_db), dim3(256), 0, s, ra, "chap_wgrad(reduce)");
 }

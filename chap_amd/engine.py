@@ -124,6 +124,15 @@ def lazy_gradient_enabled():
     return os.environ.get("CHAP_LAZY_GRAD", "0") == "1"
 
 
+def wgrad_defer_enabled():
+    """CHAP_WGRAD_DEFER=1 (lab / A-B switch, default 0): the slab reductions of a backward pass's weight gradients as ONE multi-layer launch at its
+    end (chap_wgrad_reduce_multi) instead of one launch per layer.  Bit-identical; whole iteration, two on-box A/B pairs: 2D 6.75-6.78 ->
+    6.73-6.75 ms (noise level), 3D 14.99-15.00 -> 15.12-15.16 ms (slower: the reductions no longer overlap the input-gradient convs that follow
+    them, they all sit at the end of the chain)."""
+    import os
+    return os.environ.get("CHAP_WGRAD_DEFER", "0") == "1"
+
+
 def grouping_mode():
     """CHAP_GROUP (lab / A-B switch): 0 = never group (round 2: decoders back to back where a pass cannot fork), 1 (default) = group the
     two decoders' same-shaped layers in the passes that cannot fork a second stream, 2 = group in every pass (no second stream)."""
@@ -505,6 +514,9 @@ class Executor:
             gr = self.m.grad_views_of(grad_buffer) if grad_buffer is not None else self.m._grad_views()
         dev = S.x.device
         N = S.x.shape[0]
+        # the slab reductions of the weight gradients are not needed before the optimizer: ONE multi-layer launch at the end of the pass instead
+        # of one launch per layer on its chain (CHAP_WGRAD_DEFER=0: the immediate reduction of rounds 1-2)
+        deferred = [] if (need_wgrad and wgrad_defer_enabled()) else None
         contrib = {}        # value name -> list of (tensor, coff, index of the op whose backward produced it)
         okey = {id(op): i for i, op in enumerate(prog.ops)}
 
@@ -623,7 +635,7 @@ class Executor:
                     if S.xpad is not None:
                         taps = 3 ** dims
                         ops.wgrad([Lazy(S.xpad)], v if bgrad else g, gr[op.w], (1, taps, taps), grid=(n, D, H, W), in_dims=(D, H, W),
-                                  ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=1, bgrad=bgrad)
+                                  ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=1, bgrad=bgrad, defer=deferred)
                     else:
                         ops.conv_c1_bwd(gt, sd[op.w], S.x.view(n, D, H, W), dims=dims, dx=None,
                                         dw=gr[op.w], db=gr[op.b] if op.b else None)
@@ -640,7 +652,7 @@ class Executor:
                 taps = op.ksize ** dims
                 if need_wgrad:
                     ops.wgrad(srcs, v if bgrad else g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
-                              ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid, bgrad=bgrad)
+                              ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid, bgrad=bgrad, defer=deferred)
                 wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
@@ -649,7 +661,7 @@ class Executor:
                 gdd = S.dims[op.out]
                 if need_wgrad:
                     ops.wgrad(srcs, v if bgrad else g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
-                              ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, bgrad=bgrad)
+                              ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, bgrad=bgrad, defer=deferred)
                 wp = self._pack(op, L.PACK_DOWN_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, nsub * ctot, dsrc, grid=(n,) + gdd, in_dims=gdd, ksize=1, stride=1, dims=dims,
@@ -660,7 +672,7 @@ class Executor:
                 if need_wgrad:
                     assert len(srcs) == 1
                     ops.wgrad([g], srcs[0], gr[op.w], (1, nsub, op.cout * nsub), grid=(n, sd_, sh_, sw_), in_dims=fine,
-                              ksize=2, stride=2, dims=dims)
+                              ksize=2, stride=2, dims=dims, defer=deferred)
                     if op.b:
                         ops.channel_sum(g, gr[op.b])
                 wp = self._pack(op, L.PACK_DECONV_DGRAD, dtype, sd)
@@ -697,6 +709,8 @@ class Executor:
         else:
             for op in rev:
                 yield [lambda op=op: bwd_op(op)]
+        if deferred:            # (runs when the driver asks for the next step, outside any launch region)
+            ops.wgrad_reduce_multi(deferred)
         return dx
 
     @staticmethod

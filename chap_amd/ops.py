@@ -139,7 +139,7 @@ def conv_c1_bwd(g, w, x, *, dims, dx=None, dw=None, db=None):
     L.call("chap_conv_c1_bwd", p, _stream())
 
 
-def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine=0, db=None, kc_valid=0, kn_valid=0, bgrad=None):
+def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine=0, db=None, kc_valid=0, kn_valid=0, bgrad=None, defer=None):
     """bgrad (chap_bgrad_t, "lazy gradient"): dict(dy=(tensor, coff), sums=, mean=, invstd=, gamma=, count=, gout=) -- `b` is then the RAW conv
     output with its forward transform and the B operand g = BatchNorm / activation backward of dy is computed while it is staged (and stored
     to gout for the input-gradient conv): chap_act_bwd_apply folded into this launch."""
@@ -164,7 +164,19 @@ def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine
     nbytes = L.size_of("chap_wgrad_ws", p)
     ws = L.hold_empty(max(nbytes, 16), dtype=torch.uint8, device=dw.device)
     p.ws, p.ws_bytes = ws.data_ptr(), nbytes
+    if defer is not None:        # `defer`: a list; the slab reduction is left to wgrad_reduce_multi(defer) (one launch for many layers)
+        import ctypes as C
+        entry = L.WgradReduceEntry()
+        p.deferred = C.pointer(entry)
+        defer.append((entry, ws))               # the workspace lives until the reduction has been enqueued
     L.call("chap_wgrad", p, _stream())
+
+
+def wgrad_reduce_multi(defer):
+    """Reduce the slabs of every weight gradient recorded in `defer` (see wgrad) and empty the list."""
+    if defer:
+        L.wgrad_reduce_multi([e for e, _ in defer], _stream())
+        del defer[:]
 
 
 def bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, count, eps, momentum,

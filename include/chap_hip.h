@@ -194,6 +194,18 @@ typedef struct {
     void*        gout;                           /* g is also written here, or NULL                                                       */
 } chap_bgrad_t;
 
+/* Deferred slab reduction (round 3): with `deferred` != NULL chap_wgrad launches the partial-slab kernel only and fills *deferred (a HOST
+ * struct) with what its reduction needs; chap_wgrad_reduce_multi then reduces the slabs of MANY layers in one launch (up to 16 per grid) -- the
+ * weight gradients are not needed before the optimizer, so a backward pass issues one reduction at its end instead of one launch per layer on
+ * its chain (73 / 110 per 2D / 3D iteration).  Same per-layer summation order as the immediate reduction: bit-identical.  The workspaces must
+ * stay alive until chap_wgrad_reduce_multi has been enqueued. */
+typedef struct {
+    const float* ws; const float* ws_db; float* dw; float* db;
+    int64_t s_tap, s_kc, s_kn;
+    int32_t nsplit, taps, Ca, Cb, kc_valid, kn_valid;
+    int32_t nb_dw, nblocks, e4;            /* launch geometry of this entry's reduction (filled by chap_wgrad) */
+} chap_wgrad_reduce_entry;
+
 typedef struct {
     chap_src_t  a[2];          /* strided operand, up to two concatenated/added sources           */
     int32_t     na;  int32_t combine;
@@ -208,9 +220,11 @@ typedef struct {
     void*       ws;  size_t ws_bytes;
     int32_t     dtype;
     chap_bgrad_t bgrad;        /* B computed on the fly from (dy, b = raw x): see chap_bgrad_t; bgrad.dy == NULL: B is read from b */
+    chap_wgrad_reduce_entry* deferred;   /* host pointer or NULL: see chap_wgrad_reduce_entry */
 } chap_wgrad_params;
 size_t chap_wgrad_ws(const chap_wgrad_params* p);
 int    chap_wgrad(const chap_wgrad_params* p, void* stream);
+int    chap_wgrad_reduce_multi(const chap_wgrad_reduce_entry* entries_host, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm pieces (nn.BatchNorm2d/3d, unet.py:51,55; vnet.py:21,80,110).                    */

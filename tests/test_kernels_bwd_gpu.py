@@ -388,3 +388,33 @@ def test_lazy_gradient_in_wgrad_equals_the_apply_launch(dtype, case):
     for name, t0, t1 in zip(("g", "dw", "db", "dgamma", "dbeta"), a, b):
         assert torch.equal(t0, t1), (case, name, float((t0.float() - t1.float()).abs().max()))
     assert a[0].float().abs().max() > 0 and a[1].abs().max() > 0
+
+
+def test_deferred_slab_reduction_equals_the_immediate_one():
+    """chap_wgrad(deferred=...) + chap_wgrad_reduce_multi: the slab reductions of several layers (few large slabs / many small ones, with and
+    without bias gradient, a padded head) in ONE launch give the bits of the per-layer reduction launches, and accumulate (+=) like them."""
+    from chap_amd import ops
+    from chap_amd.ops import Lazy
+    gen = torch.Generator().manual_seed(5)
+    layers = []
+    for (N, H, W, ca, cb, bias, knv) in ((12, 64, 64, 16, 16, True, 0), (2, 16, 16, 128, 64, True, 0), (3, 32, 32, 32, 32, False, 0), (2, 48, 48, 16, 16, True, 4)):
+        a = Lazy(torch.randn(N, 1, H, W, ca, generator=gen).to(DEV).to(torch.bfloat16))
+        b = Lazy(torch.randn(N, 1, H, W, cb, generator=gen).to(DEV).to(torch.bfloat16))
+        layers.append((a, b, ca, cb, bias, knv, (N, 1, H, W)))
+
+    def run(defer):
+        outs, lst = [], ([] if defer else None)
+        for a, b, ca, cb, bias, knv, grid in layers:
+            co = knv or cb
+            dw, db = torch.full((co, ca, 9), 0.5, device=DEV), (torch.full((co,), -1.0, device=DEV) if bias else None)
+            ops.wgrad([a], b, dw, (1, 9, ca * 9), grid=grid, in_dims=grid[1:], ksize=3, stride=1, dims=2, db=db, kn_valid=knv, defer=lst)
+            outs += [dw] + ([db] if bias else [])
+        if defer:
+            assert len(lst) == len(layers) and all(float(o.sum()) == o.numel() * (0.5 if o.dim() == 3 else -1.0) for o in outs)   # nothing reduced yet
+            ops.wgrad_reduce_multi(lst)
+            assert lst == []
+        torch.cuda.synchronize()
+        return outs
+
+    for x, y in zip(run(False), run(True)):
+        assert torch.equal(x, y)
