@@ -262,7 +262,7 @@ class Executor:
 
     # ---------------------------------------------------------------- forward
     def forward(self, x, **kw):
-        """x: fp32 [N, 1, *spatial] contiguous. Returns (list of planar fp32 logits, Saved|None, extras):
+        """x: fp32 [N, in_chns, *spatial] contiguous. Returns (list of planar fp32 logits, Saved|None, extras):
         extras = the activated values named in `want`, materialised as planar fp32 [N, C, *spatial]."""
         return drive([self.forward_steps(x, **kw)], torch.cuda.current_stream().cuda_stream)[0]
 
@@ -371,7 +371,7 @@ class Executor:
             if k == "c1":
                 gd = (D, H, W)
                 out = L.hold_empty(n, D, H, W, op.cout, dtype=dtype, device=dev)
-                if dtype == torch.bfloat16:
+                if dtype == torch.bfloat16 or x.shape[1] > 1:     # (in_chns > 1: the padded MFMA path in fp32 too; the scalar kernels are 1-channel)
                     xpad = L.hold_empty(n, D, H, W, 16, dtype=dtype, device=dev)
                     ops.planar_to_cl(x, xpad, cpad=16)
                     S.xpad = xpad
@@ -634,15 +634,16 @@ class Executor:
                 if need_wgrad:      # (first: with the lazy gradient it is the weight gradient that writes g)
                     if S.xpad is not None:
                         taps = 3 ** dims
-                        ops.wgrad([Lazy(S.xpad)], v if bgrad else g, gr[op.w], (1, taps, taps), grid=(n, D, H, W), in_dims=(D, H, W),
-                                  ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=1, bgrad=bgrad, defer=deferred)
+                        cin = S.x.shape[1]
+                        ops.wgrad([Lazy(S.xpad)], v if bgrad else g, gr[op.w], (1, taps, cin * taps), grid=(n, D, H, W), in_dims=(D, H, W),
+                                  ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=cin, bgrad=bgrad, defer=deferred)
                     else:
                         ops.conv_c1_bwd(gt, sd[op.w], S.x.view(n, D, H, W), dims=dims, dx=None,
                                         dw=gr[op.w], db=gr[op.b] if op.b else None)
                 if need_dx:
-                    dx = L.hold_empty_like(S.x)      # [n, 1, *spatial] fp32 == planar output with one channel
+                    dx = L.hold_empty_like(S.x)      # [n, in_chns, *spatial] fp32 == planar output
                     wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
-                    ops.conv_fwd([g], wp, None, 1, dx, grid=(n, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=dims,
+                    ops.conv_fwd([g], wp, None, S.x.shape[1], dx, grid=(n, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=dims,
                                  out_planar=True, out_f32=True)
                 return
             srcs = [V[s] for s in op.srcs]

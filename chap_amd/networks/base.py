@@ -42,6 +42,7 @@ class ChapNet(nn.Module):
 
     compute_dtype = torch.float32     # torch.bfloat16 = throughput mode (bench); fp32 = parity mode
     dims = 2
+    in_chns = 1                       # input channels (1 on the CHAP hot path: ACDC slices, LA volumes); <= 16
 
     def _finish_init(self, program):
         self._exec = Executor(self, program)
@@ -229,8 +230,8 @@ class ChapNet(nn.Module):
         gens = []
         for ps in passes:
             x = ps["x"]
-            if x.dim() != self.dims + 2 or x.shape[1] != 1:
-                raise ValueError("chap_amd: expected input [N, 1, %s], got %s" % (", ".join("*" * self.dims), tuple(x.shape)))
+            if x.dim() != self.dims + 2 or x.shape[1] != self.in_chns:
+                raise ValueError("chap_amd: expected input [N, %d, %s], got %s" % (self.in_chns, ", ".join("*" * self.dims), tuple(x.shape)))
             if x.dtype != torch.float32 or not x.is_contiguous():
                 x = x.float().contiguous()
             gens.append(self._exec.forward_steps(x.detach(), train=self.training, dtype=self.compute_dtype, save=bool(ps.get("save", False)),
@@ -271,8 +272,8 @@ class ChapNet(nn.Module):
 
     # ------------------------------------------------------------------ running the program
     def _run(self, x, *, drop_masks=None, update_stats=True, want=(), grad_buffer=None, perturb=None):
-        if x.dim() != self.dims + 2 or x.shape[1] != 1:
-            raise ValueError("chap_amd: expected input [N, 1, %s], got %s" % (", ".join("*" * self.dims), tuple(x.shape)))
+        if x.dim() != self.dims + 2 or x.shape[1] != self.in_chns:
+            raise ValueError("chap_amd: expected input [N, %d, %s], got %s" % (self.in_chns, ", ".join("*" * self.dims), tuple(x.shape)))
         self._ensure_flat()
         if x.dtype != torch.float32 or not x.is_contiguous():
             x = x.float().contiguous()

@@ -64,10 +64,10 @@ def _block_ops(ops, pre, src, out, cin, cout, drop_p, first=False, combine=0):
     ops.append(Op("conv", out, [mid], ksize=3, w=pre + ".4.weight", b=pre + ".4.bias", bn=pre + ".5", slope=SLOPE, cin=cout, cout=cout))
 
 
-def build_program(n_class, decoders, enc_root="encoder"):
+def build_program(n_class, decoders, enc_root="encoder", in_chns=1):
     """decoders: list of (root name, bilinear?[, plus?])."""
     ops = []
-    _block_ops(ops, enc_root + ".in_conv.conv_conv", None, "e0", 1, FT[0], DROP[0], first=True)
+    _block_ops(ops, enc_root + ".in_conv.conv_conv", None, "e0", in_chns, FT[0], DROP[0], first=True)
     for i in range(1, 5):
         ops.append(Op("pool", "p%d" % i, ["e%d" % (i - 1)]))
         _block_ops(ops, "%s.down%d.maxpool_conv.1.conv_conv" % (enc_root, i), ["p%d" % i], "e%d" % i, FT[i - 1], FT[i], DROP[i])
@@ -107,8 +107,9 @@ class DualDecoder(ChapNet):
 
     def __init__(self, in_chns, class_num, args):
         super().__init__()
-        if in_chns != 1:
-            raise NotImplementedError("chap_amd: in_chns=%d (the CHAP hot path is single-channel)" % in_chns)
+        if not 1 <= in_chns <= 16:
+            raise NotImplementedError("chap_amd: in_chns=%d (1..16: the first layer runs on the input zero-padded to 16 channels)" % in_chns)
+        self.in_chns = in_chns
         self.decoder_type = args["decoder_type"]
         if self.decoder_type not in ("mcnet", "same", "plus"):
             raise ValueError("chap_amd: decoder_type=%r (same | plus | mcnet, unet.py:270-275)" % self.decoder_type)
@@ -116,7 +117,7 @@ class DualDecoder(ChapNet):
         self.decoder1 = _decoder(class_num, True)
         bil2, plus2 = self.decoder_type in ("same", "plus"), self.decoder_type == "plus"      # unet.py:270-275
         self.decoder2 = _decoder(class_num, bil2, plus2)
-        self._finish_init(build_program(class_num, [("decoder1", True), ("decoder2", bil2, plus2)]))
+        self._finish_init(build_program(class_num, [("decoder1", True), ("decoder2", bil2, plus2)], in_chns=in_chns))
 
     def forward(self, x, with_feat=False, dropout=False, dropout_level=None, scores=None, comp_dropout=False,
                 drop_masks=None, update_stats=True, grad_buffer=None, drop_uniforms=None, drop_branches=None):
@@ -180,11 +181,12 @@ class UNet(ChapNet):
 
     def __init__(self, in_chns, class_num):
         super().__init__()
-        if in_chns != 1:
-            raise NotImplementedError("chap_amd: in_chns=%d" % in_chns)
+        if not 1 <= in_chns <= 16:
+            raise NotImplementedError("chap_amd: in_chns=%d (1..16)" % in_chns)
+        self.in_chns = in_chns
         self.encoder = _encoder(in_chns)
         self.decoder = _decoder(class_num, True)
-        self._finish_init(build_program(class_num, [("decoder", True)]))
+        self._finish_init(build_program(class_num, [("decoder", True)], in_chns=in_chns))
 
     def forward(self, x, with_feats=False, drop_masks=None, update_stats=True, grad_buffer=None):
         if with_feats:      # unet.py:513-520 -> Decoder.forward(feature, True) (:187-190): (logits, the last decoder feature [N, 16, H, W])

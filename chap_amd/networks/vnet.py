@@ -67,7 +67,7 @@ def _decoder(n_classes, nf, up_type):
     return dec
 
 
-def build_program(n_classes, nf, decoders, has_dropout):
+def build_program(n_classes, nf, decoders, has_dropout, n_channels=1):
     """decoders: list of (root, up_type)."""
     ops = []
 
@@ -83,7 +83,7 @@ def build_program(n_classes, nf, decoders, has_dropout):
                 ops.append(Op("conv", name, cur, ksize=3, combine=combine if s == 0 else 0, **kw))
             cur = [name]
 
-    c = 1
+    c = n_channels
     x = None
     for i, (name, n) in enumerate(STAGES):
         co = nf * (2 ** i)
@@ -122,8 +122,8 @@ def build_program(n_classes, nf, decoders, has_dropout):
 def _check(normalization, has_residual, n_channels):
     if normalization != "batchnorm" or has_residual:
         raise NotImplementedError("chap_amd: only normalization='batchnorm', has_residual=False (net_factory_3d's configuration) is built")
-    if n_channels != 1:
-        raise NotImplementedError("chap_amd: n_channels=%d (the CHAP hot path is single-channel)" % n_channels)
+    if not 1 <= n_channels <= 16:
+        raise NotImplementedError("chap_amd: n_channels=%d (1..16: the first layer runs on the input zero-padded to 16 channels)" % n_channels)
 
 
 class DualDecoder3d(ChapNet):
@@ -134,11 +134,12 @@ class DualDecoder3d(ChapNet):
     def __init__(self, n_channels=3, n_classes=2, n_filters=16, normalization="none", has_dropout=False, has_residual=False, args=None):
         super().__init__()
         _check(normalization, has_residual, n_channels)
+        self.in_chns = n_channels
         self.encoder = _encoder(n_channels, n_filters)
         self.decoder1 = _decoder(n_classes, n_filters, 1)
         self.decoder2 = _decoder(n_classes, n_filters, 0)
         self.encoder.has_dropout = self.decoder1.has_dropout = self.decoder2.has_dropout = has_dropout
-        self._finish_init(build_program(n_classes, n_filters, [("decoder1", 1), ("decoder2", 0)], has_dropout))
+        self._finish_init(build_program(n_classes, n_filters, [("decoder1", 1), ("decoder2", 0)], has_dropout, n_channels))
 
     def forward(self, input, drop_masks=None, update_stats=True, grad_buffer=None):
         out = self._run(input, drop_masks=drop_masks, update_stats=update_stats, grad_buffer=grad_buffer)
@@ -153,10 +154,11 @@ class VNet(ChapNet):
     def __init__(self, n_channels=3, n_classes=2, n_filters=16, normalization="none", has_dropout=False, has_residual=False):
         super().__init__()
         _check(normalization, has_residual, n_channels)
+        self.in_chns = n_channels
         self.encoder = _encoder(n_channels, n_filters)
         self.decoder = _decoder(n_classes, n_filters, 0)
         self.encoder.has_dropout = self.decoder.has_dropout = has_dropout
-        self._finish_init(build_program(n_classes, n_filters, [("decoder", 0)], has_dropout))
+        self._finish_init(build_program(n_classes, n_filters, [("decoder", 0)], has_dropout, n_channels))
 
     def forward(self, input, drop_masks=None, update_stats=True, grad_buffer=None):
         return self._run(input, drop_masks=drop_masks, update_stats=update_stats, grad_buffer=grad_buffer)[0]

@@ -212,3 +212,43 @@ def test_dualdecoder_plus_and_same(golden_dir, decoder_type, dtype):
         for i, n in enumerate(g["grad_pick_names"]):
             want = g["%s_train64_grad_pick%d" % (dt, i)]
             assert relerr(grads[str(n)].grad, want) < 1e-1 and cosine(grads[str(n)].grad, want) > 0.999, n
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_multi_channel_input(dims):
+    """in_chns > 1 (net_factory's second argument, net_factory.py:11 / net_factory_3d.py:7; the CHAP runs use 1): the first layer runs on the
+    input zero-padded to 16 channels in both dtypes.  Eval logits, input gradient and the first layer's weight gradient against the oracle."""
+    from chap_amd.networks import net_factory_3d
+    from oracle import nets as onets
+    g = torch.Generator().manual_seed(41)
+    if dims == 2:
+        cin, x = 3, torch.rand(2, 3, 32, 32, generator=g)
+        state = oinit.dual_decoder_2d_state(77, in_chns=cin)
+        m = net_factory("dualdecoder", cin, 4, DEV, {"decoder_type": "mcnet"})
+        ofn, wkey = onets.dual_decoder_2d, "encoder.in_conv.conv_conv.0.weight"
+    else:
+        cin, x = 2, torch.rand(1, 2, 16, 32, 16, generator=g)
+        state = oinit.dual_decoder_3d_state(78, in_chns=cin)
+        m = net_factory_3d("dualdecoder", cin, 2, "test", DEV)
+        ofn, wkey = onets.dual_decoder_3d, "encoder.block_one.conv.0.weight"
+    m.load_state_dict(state, strict=True)
+    m.eval()
+    sd = {k: v.clone() for k, v in state.items()}
+    sd[wkey].requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    o = ofn(sd, xr, train=False)
+    cot = [torch.randn(t.shape, generator=g) for t in o]
+    sum((a * b).sum() for a, b in zip(o, cot)).backward()
+    xd = x.to(DEV).requires_grad_(True)
+    h = m(xd)
+    torch.autograd.backward(h, [c.to(DEV) for c in cot])
+    for a, b in zip(h, o):
+        assert relerr(a, b.detach()) < 1e-4
+    assert relerr(xd.grad, xr.grad) < 1e-2 and cosine(xd.grad, xr.grad) > 0.9999
+    assert relerr(dict(m.named_parameters())[wkey].grad, sd[wkey].grad) < (2e-3 if dims == 2 else 5e-3)      # measured 3D: 2.4e-3 (a sum over 8 192 voxels through 40 fp32 layers)
+    m.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        hb = m(x.to(DEV))
+    assert relerr(hb[0], o[0].detach()) < 6e-2
+    with pytest.raises(ValueError):
+        m(torch.rand(1, 1, *x.shape[2:], device=DEV))
