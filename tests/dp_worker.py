@@ -41,22 +41,43 @@ def main():
     ap.add_argument("--mode", default="eager", choices=["eager", "graph"])
     ap.add_argument("--overlap", type=int, default=1)
     ap.add_argument("--no-dp", action="store_true", help="the same iteration without a process group (reference for world 1)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: every rank on cuda:0 (a 1-GPU box), the gradient buckets "
+                    "all-reduced through host memory -- the data-parallel LOGIC of a world > 1 on real kernels without a second GPU")
     a = ap.parse_args()
     from chap_amd.networks import DualDecoder
     from chap_amd.parallel import DataParallelSync
     from chap_amd.train import ChapStep
     from oracle import init as oinit
-    dev = torch.device("cuda", a.rank % torch.cuda.device_count())
+    dev = torch.device("cuda", 0 if a.backend == "gloo" else a.rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    xdist = dist
     if not a.no_dp:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(a.port), RANK=str(a.rank), WORLD_SIZE=str(a.world))
-        dist.init_process_group("nccl", rank=a.rank, world_size=a.world, device_id=dev)
+        if a.backend == "gloo":
+            dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
+
+            class _Done:
+                def wait(self):
+                    pass
+
+            class HostStaged:          # torch.distributed's interface as DataParallelSync uses it, staged through host memory
+                ReduceOp = dist.ReduceOp
+
+                @staticmethod
+                def all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+                    c = t.detach().cpu()                      # (synchronises the current stream: the bucket is final)
+                    dist.all_reduce(c, op=op, group=group)
+                    t.copy_(c)
+                    return _Done()
+            xdist = HostStaged
+        else:
+            dist.init_process_group("nccl", rank=a.rank, world_size=a.world, device_id=dev)
     m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(dev).train()
     m.load_state_dict(oinit.dual_decoder_2d_state(301), strict=True)
     step = ChapStep(m, ARGS, world_size=1 if a.no_dp else a.world)
     step.iter_num = IT0
     if not a.no_dp:
-        step.grad_sync = DataParallelSync(step.grad_both, dist, overlap=bool(a.overlap))
+        step.grad_sync = DataParallelSync(step.grad_both, xdist, overlap=bool(a.overlap))
     vol, lab, inj, box = shard_inputs(a.rank)
     vol, lab = vol.to(dev), lab.to(dev)
     inj = {k: ({kk: vv.permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(dev) for kk, vv in v.items()} if k.startswith("drop") else v.to(dev)) for k, v in inj.items()}

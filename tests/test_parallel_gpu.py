@@ -50,17 +50,24 @@ def test_one_rank_nccl_group_equals_the_plain_step(tmp_path, mode, overlap):
     assert torch.equal(ref["mom"], got["mom"])
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
+@pytest.mark.parametrize("backend", ["nccl", "gloo"])
 @pytest.mark.parametrize("mode", ["eager", "graph"])
-def test_two_ranks_hold_identical_parameters_equal_to_the_mean_of_shard_gradients(tmp_path, mode):
+def test_two_ranks_hold_identical_parameters_equal_to_the_mean_of_shard_gradients(tmp_path, mode, backend):
+    """backend nccl: one rank per GPU over RCCL (needs two GPUs).  backend gloo: BOTH ranks on cuda:0 of a 1-GPU box, the gradient buckets
+    all-reduced through host memory (tests/dp_worker.py) -- the world-2 logic of ChapStep / DataParallelSync (shards, fold or overlap
+    schedule, 1/world scaling in the fused SGD, per-replica BatchNorm) on the real kernels, without RCCL."""
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
     from oracle import init as oinit
     from oracle import train_step as ots
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dp_worker as W
-    port = 29900 + os.getpid() % 90
-    _wait([_run(["--rank", r, "--world", 2, "--out", tmp_path, "--mode", mode, "--overlap", 1, "--port", port]) for r in range(2)])
-    r0 = torch.load(os.path.join(tmp_path, "rank0_%s_1.pt" % mode))
-    r1 = torch.load(os.path.join(tmp_path, "rank1_%s_1.pt" % mode))
+    port = 29900 + os.getpid() % 90 + (5 if backend == "gloo" else 0) + (1 if mode == "graph" else 0)
+    overlap = 1 if backend == "nccl" else 0                     # (gloo staging has no streams to overlap: the default fold schedule)
+    _wait([_run(["--rank", r, "--world", 2, "--out", tmp_path, "--mode", mode, "--overlap", overlap, "--port", port, "--backend", backend]) for r in range(2)])
+    r0 = torch.load(os.path.join(tmp_path, "rank0_%s_%d.pt" % (mode, overlap)))
+    r1 = torch.load(os.path.join(tmp_path, "rank1_%s_%d.pt" % (mode, overlap)))
+    assert float(r0["buckets"].abs().max()) == 0.0 and float(r1["buckets"].abs().max()) == 0.0
     # parameters (not BatchNorm running statistics: those are per replica, DDP semantics) are identical on the two ranks
     for k in r0["model"]:
         if not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
