@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs (config 3 = 3D bf16, and the 2D fp32 parity mode) of the default run")
     ap.add_argument("--extra-steps", type=int, default=10)
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks (--gpus N without a launcher): overall limit in seconds")
+    ap.add_argument("--rehearse-one-gpu", action="store_true", help="run the --gpus N ranks on cuda:0 together (1-GPU box), gradients all-reduced through host "
+                    "memory over gloo: exercises the whole multi-rank path of this script end to end; the value is NOT a scaling measurement")
     ap.add_argument("--dry-run", action="store_true", help="rehearse the multi-rank plumbing on the CPU (gloo, no GPU, no model): rendezvous, barriers, "
                     "MAX-over-ranks timing, rank 0's JSON line -- what tests/test_parallel_cpu.py drives")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="(dry run) this rank exits with code 3 before the rendezvous")
@@ -436,6 +438,8 @@ def main():
     assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node == --gpus (or run `python bench.py --gpus N` plainly: it starts the ranks itself)" % (args.gpus, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in chap_amd)")
+    if args.rehearse_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -444,7 +448,10 @@ def main():
         import torch.distributed as dist
         if force_dp and "RANK" not in os.environ:
             os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29531"))
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     d3 = args.config == "3d"
     B = args.batch or (4 if d3 else 24)
@@ -457,7 +464,11 @@ def main():
     model, step, dtype = build_step(args.config, args.dtype, B, sp, args.vat_iters, extra, world, dev)
     if dist is not None:
         from chap_amd.parallel import DataParallelSync
-        step.grad_sync = DataParallelSync(step.grad_both, dist, overlap=args.dp_overlap)
+        if args.rehearse_one_gpu:
+            from chap_amd.parallel import HostStagedDist
+            step.grad_sync = DataParallelSync(step.grad_both, HostStagedDist(dist), overlap=False)
+        else:
+            step.grad_sync = DataParallelSync(step.grad_both, dist, overlap=args.dp_overlap)
     vol, lab = synthetic(args.config, 1337 + rank, B, sp, dev)      # each rank: its own shard (weak scaling)
     use_graph = not args.no_graph
     log("model + data ready (B=%d, %s, %s)" % (B, "x".join(map(str, sp)), args.dtype))
@@ -467,7 +478,7 @@ def main():
         run = lambda: step.replay(vol, lab)                                    # noqa: E731
     else:
         run = lambda: step.step(vol, lab)                                      # noqa: E731
-    dt, out = time_steps(run, args.steps, args.warmup, dist, dev)
+    dt, out = time_steps(run, args.steps, args.warmup, dist, torch.device("cpu") if args.rehearse_one_gpu else dev)
     log("timed region done: %.2f ms/step" % (dt / args.steps * 1e3))
     finite = bool(torch.isfinite(out["vat_loss"]).all()) and all(bool(torch.isfinite(l).all()) for l in out["mix_losses"])
     vps = B * world * args.steps / dt
@@ -488,6 +499,8 @@ def main():
                            "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": use_graph, "losses_finite": finite,
                            "grad_exchange": None if world == 1 and not force_dp else ("rccl all-reduce, bucket 0 overlapped with the VAT chain" if args.dp_overlap else "rccl all-reduce of the folded buckets")},
                 "roofline": roof}
+        if args.rehearse_one_gpu:
+            line["rehearsal"] = "%d ranks on ONE GPU, gradients through host memory (gloo): exercises the multi-rank path, NOT a scaling measurement" % world
         # the other single-GPU configurations on the driver's line (default run only): BASELINE config 3 (3D, bf16) and the fp32 parity mode
         default_run = world == 1 and not force_dp and not d3 and args.dtype == "bf16" and not args.batch and H == 256 and args.vat_iters == 1 and use_graph and not extra
         if default_run and not args.no_extra:

@@ -61,3 +61,22 @@ class DataParallelSync:
             if w is not None:
                 w.wait()
         self.work0 = self.work = None
+
+
+class HostStagedDist:
+    """torch.distributed as DataParallelSync uses it (`all_reduce`, `ReduceOp`), with every tensor staged through host memory: lets
+    several ranks share ONE GPU over a CPU backend (gloo) -- rehearsals of the multi-rank paths on a 1-GPU box (`bench.py --gpus N
+    --rehearse-one-gpu`, tests/dp_worker.py --backend gloo).  Not a product path: no overlap, a host round trip per exchange."""
+
+    def __init__(self, dist):
+        self._dist, self.ReduceOp = dist, dist.ReduceOp
+
+    class _Done:
+        def wait(self):
+            pass
+
+    def all_reduce(self, t, op=None, group=None, async_op=False):
+        c = t.detach().cpu()                      # (synchronises the current stream: the buffer is final)
+        self._dist.all_reduce(c, op=self._dist.ReduceOp.SUM if op is None else op, group=group)
+        t.copy_(c)
+        return self._Done()

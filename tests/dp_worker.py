@@ -56,20 +56,8 @@ def main():
         if a.backend == "gloo":
             dist.init_process_group("gloo", rank=a.rank, world_size=a.world)
 
-            class _Done:
-                def wait(self):
-                    pass
-
-            class HostStaged:          # torch.distributed's interface as DataParallelSync uses it, staged through host memory
-                ReduceOp = dist.ReduceOp
-
-                @staticmethod
-                def all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
-                    c = t.detach().cpu()                      # (synchronises the current stream: the bucket is final)
-                    dist.all_reduce(c, op=op, group=group)
-                    t.copy_(c)
-                    return _Done()
-            xdist = HostStaged
+            from chap_amd.parallel import HostStagedDist
+            xdist = HostStagedDist(dist)
         else:
             dist.init_process_group("nccl", rank=a.rank, world_size=a.world, device_id=dev)
     m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(dev).train()

@@ -91,3 +91,21 @@ def test_two_ranks_hold_identical_parameters_equal_to_the_mean_of_shard_gradient
         num += float(((upd_o - upd_h) ** 2).sum())
         den += float((upd_o ** 2).sum())
     assert (num / den) ** 0.5 < 0.02, (num / den) ** 0.5
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on a 1-GPU box: the script starts its two rank processes itself (self_launch), both ranks run the
+    captured iteration on cuda:0 (--rehearse-one-gpu: gradients all-reduced through host memory over gloo), barriers + MAX-over-ranks timing,
+    and rank 0 prints the ONE JSON line with the whole-job value.  A rehearsal of the N > 1 path, not a measurement."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    port = 29400 + os.getpid() % 300
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline", "--master-port", str(port), "--launch-timeout", "400"], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["scaling"] == "weak" and d["config"]["global_batch"] == 48 and d["config"]["parallelism"] == "dp2"
+    assert d["config"]["losses_finite"] and d["value"] > 0 and "rehearsal" in d
+    assert abs(d["value"] - 48 * 1000.0 / d["ms_per_step"]) / d["value"] < 1e-3          # whole-job volumes/s = global batch / step time
