@@ -345,12 +345,15 @@ class group:
 
     def __exit__(self, et, ev, tb):
         if self.enabled:
-            rc = lib().chap_group_end()         # also on an exception: leaves the recording state
+            if et is not None:                  # the body failed: drop what was recorded (its buffers are released with `held`), nothing is launched
+                lib().chap_group_cancel()
+                group.held = None
+                return False
+            rc = lib().chap_group_end()
             group.held = None
-            if rc < 0 and et is None:
+            if rc < 0:
                 raise ChapError("chap_group_end failed (%d): %s" % (rc, lib().chap_last_error().decode()))
-            if rc > 0:
-                group.launched += rc
+            group.launched += rc
         return False
 
 

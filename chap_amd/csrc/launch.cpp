@@ -73,6 +73,14 @@ extern "C" int chap_group_end(void) {
     return rc == CHAP_OK ? launched : rc;
 }
 
+// Leaves the recording state WITHOUT issuing anything (the caller failed half-way through a region: its buffers are about to be released).
+extern "C" int chap_group_cancel(void) {
+    if (!G.on) { chap_set_error("chap_group_cancel: not recording"); return CHAP_EINVAL; }
+    G.on = false;
+    G.lanes.clear();
+    return CHAP_OK;
+}
+
 namespace { thread_local const float* g_stats_ptr = nullptr; thread_local int g_stats_slots = 0; }
 void chap_note_stats_slots(const float* stats, int slots) { g_stats_ptr = stats; g_stats_slots = slots; }
 int chap_known_stats_slots(const float* stats) {      // one-shot: only the finalize call right behind the conv may use the note

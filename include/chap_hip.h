@@ -471,6 +471,7 @@ int chap_grad_sim(const chap_gradsim_params* p, void* stream);
 int chap_group_begin(void* stream);
 int chap_group_next_lane(void);
 int chap_group_end(void);
+int chap_group_cancel(void);   /* leave the region without issuing what was recorded (error paths of the caller) */
 
 /* Bandwidth calibration helper (tools/membw.py): grid-stride float4 copy with `blocks` blocks of 256. */
 int chap_debug_copy(const void* src, void* dst, int64_t bytes, int32_t blocks, void* stream);

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.chap_abi_version() == _lib.ABI_VERSION == 5
     # every entry point bound in the ctypes tables is declared in the header and vice versa
     bound = set(_lib._SIGS) | set(_lib._SIZE_FNS) | {"chap_last_error", "chap_abi_version", "chap_debug_copy", "chap_pack_describe", "chap_pack_multi",
-                                                                "chap_group_begin", "chap_group_next_lane", "chap_group_end", "chap_wgrad_reduce_multi"}
+                                                                "chap_group_begin", "chap_group_next_lane", "chap_group_end", "chap_group_cancel", "chap_wgrad_reduce_multi"}
     assert bound == set(names), (bound ^ set(names))
 
 
@@ -228,6 +228,12 @@ def test_group_region_state_machine_without_a_gpu():
     assert lib.chap_group_end() == 0                      # nothing recorded: zero grids
     assert lib.chap_group_end() < 0 and b"not recording" in lib.chap_last_error()
     assert lib.chap_group_next_lane() < 0
+    assert lib.chap_group_cancel() < 0
+    assert lib.chap_group_begin(None) == 0 and lib.chap_group_cancel() == 0 and lib.chap_group_end() < 0      # cancelled: no region left
+    with pytest.raises(KeyError):
+        with _lib.group(None):
+            raise KeyError("body failed")
+    assert _lib.group.held is None and lib.chap_group_begin(None) == 0 and lib.chap_group_end() == 0             # the failed region was left
     with _lib.group(None) as g:                           # the Python wrapper: same calls, held tensors dropped at exit
         g.next_lane()
         assert _lib.group.held == []
