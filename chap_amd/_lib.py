@@ -230,7 +230,7 @@ _SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParam
 _lib = None
 
 
-ABI_VERSION = 5            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
+ABI_VERSION = 6            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
 
 
 class ChapError(RuntimeError):
@@ -317,6 +317,16 @@ def pack_multi(entries_dev_ptr, n, max_total, stream):
         raise ChapError("chap_pack_multi failed (%d): %s" % (rc, L.chap_last_error().decode()))
 
 
+_holders = []       # the `held` lists of the open regions (group / branches / leaves), see hold()
+
+
+def _drop_holder(h):
+    for i, o in enumerate(_holders):
+        if o is h:
+            del _holders[i]
+            return
+
+
 class group:
     """`with group(stream) as g: ...lane 0...; g.next_lane(); ...lane 1...`: chap_group_begin / _next_lane / _end (chap_hip.h):
     the launches of the lanes are recorded and issued together, same-shaped ones as one grid.  `enabled=False` (or one lane
@@ -330,6 +340,7 @@ class group:
     def __enter__(self):
         if self.enabled:
             group.held = []
+            _holders.append(group.held)
             L = lib()
             L.chap_group_begin.argtypes = [_vp]
             rc = L.chap_group_begin(_vp(self.stream))
@@ -347,13 +358,124 @@ class group:
         if self.enabled:
             if et is not None:                  # the body failed: drop what was recorded (its buffers are released with `held`), nothing is launched
                 lib().chap_group_cancel()
+                _drop_holder(group.held)
                 group.held = None
                 return False
             rc = lib().chap_group_end()
+            _drop_holder(group.held)
             group.held = None
             if rc < 0:
                 raise ChapError("chap_group_end failed (%d): %s" % (rc, lib().chap_last_error().decode()))
             group.launched += rc
+        return False
+
+
+def _capture_call(name, stream, *rest):
+    L = lib()
+    fn = getattr(L, name)
+    fn.restype, fn.argtypes = C.c_int, [_vp] + [C.c_int32] * len(rest)
+    rc = fn(_vp(stream), *rest)
+    if rc < 0:
+        raise ChapError("%s failed (%d): %s" % (name, rc, L.chap_last_error().decode()))
+    return rc == 1
+
+
+def capture_mark(stream, slot, accumulate=False):
+    """chap_capture_mark: slot := (slot U) the capture dependency set of `stream`.  True when applied, False when not capturing."""
+    return _capture_call("chap_capture_mark", stream, slot, 1 if accumulate else 0)
+
+
+def capture_goto(stream, slot):
+    return _capture_call("chap_capture_goto", stream, slot)
+
+
+def capture_join(stream, slot):
+    return _capture_call("chap_capture_join", stream, slot)
+
+
+# capture-point slots used by this package (chap_hip.h: 0 .. 15, thread-local)
+SLOT_FORK, SLOT_TAIL, SLOT_LEAF_AT, SLOT_LEAVES = 0, 1, 2, 3
+
+
+class branches:
+    """`with branches(stream) as b: ...branch 1...; b.next(); ...branch 2...`: under a graph capture the two parts become PARALLEL
+    branches of the graph on the one stream (chap_capture_mark / _goto / _join); otherwise they simply run one after the other.
+    Everything allocated through hold() inside is kept alive until the join: the branches run concurrently in the graph whatever the
+    order they were captured in, so a buffer that branch 1 released must not be handed to branch 2 by the stream-ordered allocator."""
+    def __init__(self, stream, fork=SLOT_FORK, tail=SLOT_TAIL):
+        self.stream, self.fork, self.tail = stream, fork, tail
+        self.active = self.tails = False
+        self.held = []
+
+    def __enter__(self):
+        self.active = capture_mark(self.stream, self.fork)
+        if self.active:
+            _holders.append(self.held)
+        return self
+
+    def next(self):
+        if self.active:
+            capture_mark(self.stream, self.tail, accumulate=self.tails)
+            self.tails = True
+            capture_goto(self.stream, self.fork)
+
+    def __exit__(self, et, ev, tb):
+        if self.active:
+            try:
+                if et is None and self.tails:
+                    capture_join(self.stream, self.tail)
+            finally:
+                _drop_holder(self.held)
+                self.held = []
+        return False
+
+
+class leaves:
+    """Leaves off a chain under a graph capture: `with leaves(stream) as lv: ... with lv.leaf(): <launches nobody on the chain waits
+    for> ...`: the launches inside leaf() depend on what the chain had issued up to there, the chain goes on without them, and everything
+    meets again when the region ends.  Buffers allocated through hold() anywhere inside the region are kept until then.  Outside a
+    capture: plain stream order."""
+    def __init__(self, stream, at=SLOT_LEAF_AT, acc=SLOT_LEAVES, enabled=True):
+        self.stream, self.at, self.acc, self.enabled = stream, at, acc, enabled
+        self.active = self.any = False
+        self.held = []
+
+    def __enter__(self):
+        if self.enabled:
+            self.active = capture_mark(self.stream, self.at)
+            if self.active:
+                _holders.append(self.held)
+        return self
+
+    def leaf(self):
+        return _leaf(self)
+
+    def __exit__(self, et, ev, tb):
+        if self.active:
+            try:
+                if et is None and self.any:
+                    capture_join(self.stream, self.acc)
+            finally:
+                _drop_holder(self.held)
+                self.held = []
+        return False
+
+
+class _leaf:
+    def __init__(self, region):
+        self.r = region
+
+    def __enter__(self):
+        if self.r.active:
+            capture_mark(self.r.stream, self.r.at)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        r = self.r
+        if r.active and et is None:
+            capture_mark(r.stream, r.acc, accumulate=r.any)
+            r.any = True
+            capture_goto(r.stream, r.at)
         return False
 
 
@@ -363,8 +485,8 @@ def hold(t):
     back to the caching allocator and could be handed to the NEXT lane of the same region -- two lanes of one grid writing the
     same memory.  Every tensor allocated on this path goes through hold(): kept alive until chap_group_end has issued the launches
     (stream order protects it from then on).  No-op outside a region."""
-    if group.held is not None:
-        group.held.append(t)
+    for h in _holders:                      # (group regions; parallel graph branches / leaves on one stream: same reason, until the join)
+        h.append(t)
     return t
 
 

@@ -11,6 +11,8 @@ into the model's flat gradient buffer.
 
 Reference semantics followed: code/networks/unet.py:44-292, code/networks/vnet.py:8-238.
 """
+import contextlib
+
 import torch
 
 from . import _lib as L
@@ -134,10 +136,20 @@ def wgrad_defer_enabled():
 
 
 def grouping_mode():
-    """CHAP_GROUP (lab / A-B switch): 0 = never group (round 2: decoders back to back where a pass cannot fork), 1 (default) = group the
-    two decoders' same-shaped layers in the passes that cannot fork a second stream, 2 = group in every pass (no second stream)."""
+    """CHAP_GROUP (lab / A-B switch): 0 = never group (round 2: decoders back to back where a pass cannot fork), 1 = group the
+    two decoders' same-shaped layers in the passes that cannot fork a second stream, 2 = group in every pass (no second stream),
+    3 = in a captured pass that cannot fork a stream the two decoders are PARALLEL BRANCHES of the graph on the one stream
+    (chap_capture_mark / _goto / _join, _lib.branches); eager passes as in mode 1."""
     import os
     return int(os.environ.get("CHAP_GROUP", "1"))
+
+
+def wgrad_leaf_enabled():
+    """CHAP_WGRAD_LEAF=1: under a graph capture the weight-gradient launches of a backward pass (and their slab reductions) are
+    LEAVES of the graph (_lib.leaves): they depend on the chain up to their layer, the chain does not wait for them, and the pass
+    joins them at its end -- nobody needs dW before the optimizer step."""
+    import os
+    return int(os.environ.get("CHAP_WGRAD_LEAF", "0"))
 
 
 class Saved:
@@ -316,7 +328,8 @@ class Executor:
         side = self._side_stream(cur_stream) if (len(branches) > 2 and grouping_mode() != 2) else None
         if lock:
             side = None
-        zipped = self._zipped() if (side is None and len(branches) == 3 and (lock or grouping_mode() != 0)) else None
+        branching = (side is None and not lock and len(branches) == 3 and grouping_mode() == 3 and torch.cuda.is_current_stream_capturing())
+        zipped = self._zipped() if (side is None and not branching and len(branches) == 3 and (lock or grouping_mode() != 0)) else None
 
         # Dropout seeds are drawn HERE, in program order: the order in which the ops are ISSUED depends on whether this pass
         # may fork its second decoder (eager / captured, which stream), and a seed must not (round 2: the early VAT pass drew
@@ -477,6 +490,16 @@ class Executor:
             # and no second stream (which a captured pass on a forked stream could not have, see _side_stream)
             for pair in zipped:
                 yield [lambda op=op: run_dec(op) for op in pair]
+        elif branching:
+            # a captured pass on a stream that cannot fork another one: the decoders as two parallel branches of the graph on THIS stream
+            with L.branches(cur_stream.cuda_stream) as br:
+                for op in prog.ops:
+                    if op.branch == 1:
+                        run_dec(op)
+                br.next()
+                for op in prog.ops:
+                    if op.branch >= 2:
+                        run_dec(op)
         elif side is not None:
             side.wait_stream(cur_stream)
             with torch.cuda.stream(side):
@@ -526,6 +549,12 @@ class Executor:
             and eager, captured and data-parallel runs must agree bit for bit."""
             c = contrib.get(name)
             return None if not c else [(t, o) for t, o, _ in sorted(c, key=lambda e: e[2])]
+
+        lv = [None]         # the open _lib.leaves region of the stream the ops are being issued on (CHAP_WGRAD_LEAF)
+
+        def leaf(bgrad=None):
+            # (with the lazy gradient the weight gradient WRITES g for the input-gradient conv: on the chain)
+            return lv[0].leaf() if (lv[0] is not None and bgrad is None) else contextlib.nullcontext()
 
         pooled = {}         # value name -> (grad tensor, idx)
         head_g = dict(zip(prog.heads, dlogits))
@@ -632,14 +661,15 @@ class Executor:
                 gt = g.raw if (g.coff == 0 and g.C == g.ld) else None
                 assert gt is not None
                 if need_wgrad:      # (first: with the lazy gradient it is the weight gradient that writes g)
-                    if S.xpad is not None:
-                        taps = 3 ** dims
-                        cin = S.x.shape[1]
-                        ops.wgrad([Lazy(S.xpad)], v if bgrad else g, gr[op.w], (1, taps, cin * taps), grid=(n, D, H, W), in_dims=(D, H, W),
-                                  ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=cin, bgrad=bgrad, defer=deferred)
-                    else:
-                        ops.conv_c1_bwd(gt, sd[op.w], S.x.view(n, D, H, W), dims=dims, dx=None,
-                                        dw=gr[op.w], db=gr[op.b] if op.b else None)
+                    with leaf(bgrad):
+                        if S.xpad is not None:
+                            taps = 3 ** dims
+                            cin = S.x.shape[1]
+                            ops.wgrad([Lazy(S.xpad)], v if bgrad else g, gr[op.w], (1, taps, cin * taps), grid=(n, D, H, W), in_dims=(D, H, W),
+                                      ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=cin, bgrad=bgrad, defer=deferred)
+                        else:
+                            ops.conv_c1_bwd(gt, sd[op.w], S.x.view(n, D, H, W), dims=dims, dx=None,
+                                            dw=gr[op.w], db=gr[op.b] if op.b else None)
                 if need_dx:
                     dx = L.hold_empty_like(S.x)      # [n, in_chns, *spatial] fp32 == planar output
                     wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
@@ -652,8 +682,9 @@ class Executor:
             if k == "conv":
                 taps = op.ksize ** dims
                 if need_wgrad:
-                    ops.wgrad(srcs, v if bgrad else g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
-                              ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid, bgrad=bgrad, defer=deferred)
+                    with leaf(bgrad):
+                        ops.wgrad(srcs, v if bgrad else g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
+                                  ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid, bgrad=bgrad, defer=deferred)
                 wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
@@ -661,8 +692,9 @@ class Executor:
             elif k == "down":
                 gdd = S.dims[op.out]
                 if need_wgrad:
-                    ops.wgrad(srcs, v if bgrad else g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
-                              ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, bgrad=bgrad, defer=deferred)
+                    with leaf(bgrad):
+                        ops.wgrad(srcs, v if bgrad else g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
+                                  ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, bgrad=bgrad, defer=deferred)
                 wp = self._pack(op, L.PACK_DOWN_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, nsub * ctot, dsrc, grid=(n,) + gdd, in_dims=gdd, ksize=1, stride=1, dims=dims,
@@ -672,10 +704,11 @@ class Executor:
                 fine = S.dims[op.out]
                 if need_wgrad:
                     assert len(srcs) == 1
-                    ops.wgrad([g], srcs[0], gr[op.w], (1, nsub, op.cout * nsub), grid=(n, sd_, sh_, sw_), in_dims=fine,
-                              ksize=2, stride=2, dims=dims, defer=deferred)
-                    if op.b:
-                        ops.channel_sum(g, gr[op.b])
+                    with leaf():
+                        ops.wgrad([g], srcs[0], gr[op.w], (1, nsub, op.cout * nsub), grid=(n, sd_, sh_, sw_), in_dims=fine,
+                                  ksize=2, stride=2, dims=dims, defer=deferred)
+                        if op.b:
+                            ops.channel_sum(g, gr[op.b])
                 wp = self._pack(op, L.PACK_DECONV_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=fine, ksize=2, stride=2, dims=dims)
@@ -687,29 +720,53 @@ class Executor:
         side = self._side_stream(cur_stream) if (nbr > 2 and grouping_mode() != 2) else None
         if lock:
             side = None
-        zipped = self._zipped() if (side is None and nbr == 3 and (lock or grouping_mode() != 0)) else None
-        if zipped is not None:
-            for pair in reversed(zipped):
-                yield [lambda op=op: bwd_op(op) for op in pair]
-            for op in rev:
-                if op.branch == 0:
-                    yield [lambda op=op: bwd_op(op)]
-        elif side is not None:
-            side.wait_stream(cur_stream)
-            with torch.cuda.stream(side):
+        capturing = torch.cuda.is_current_stream_capturing()
+        branching = side is None and not lock and nbr == 3 and grouping_mode() == 3 and capturing
+        zipped = self._zipped() if (side is None and not branching and nbr == 3 and (lock or grouping_mode() != 0)) else None
+        # weight gradients as leaves of the captured graph (never inside a grouped launch region: lanes are issued at the region's end)
+        wl = wgrad_leaf_enabled()        # 1: every captured pass, 2: only the passes on the capture's origin stream (the iteration's long chain)
+        leafing = bool(need_wgrad and capturing and zipped is None and not lock and (wl == 1 or (wl == 2 and side is not None)))
+        with L.leaves(cur_stream.cuda_stream, enabled=leafing) as lv_main:
+            lv[0] = lv_main if lv_main.active else None
+            if zipped is not None:
+                for pair in reversed(zipped):
+                    yield [lambda op=op: bwd_op(op) for op in pair]
                 for op in rev:
-                    if op.branch >= 2:
+                    if op.branch == 0:
+                        yield [lambda op=op: bwd_op(op)]
+            elif branching:
+                with L.branches(cur_stream.cuda_stream) as br:
+                    for op in rev:
+                        if op.branch == 1:
+                            bwd_op(op)
+                    br.next()
+                    for op in rev:
+                        if op.branch >= 2:
+                            bwd_op(op)
+                for op in rev:
+                    if op.branch == 0:
                         bwd_op(op)
-            for op in rev:
-                if op.branch == 1:
-                    bwd_op(op)
-            cur_stream.wait_stream(side)
-            for op in rev:
-                if op.branch == 0:
-                    bwd_op(op)
-        else:
-            for op in rev:
-                yield [lambda op=op: bwd_op(op)]
+            elif side is not None:
+                side.wait_stream(cur_stream)
+                with torch.cuda.stream(side):
+                    # (the side stream's leaves are its own: joined before the main stream waits for it)
+                    with L.leaves(side.cuda_stream, at=L.SLOT_LEAF_AT + 2, acc=L.SLOT_LEAVES + 2, enabled=leafing) as lv_side:
+                        lv[0] = lv_side if lv_side.active else None
+                        for op in rev:
+                            if op.branch >= 2:
+                                bwd_op(op)
+                lv[0] = lv_main if lv_main.active else None
+                for op in rev:
+                    if op.branch == 1:
+                        bwd_op(op)
+                cur_stream.wait_stream(side)
+                for op in rev:
+                    if op.branch == 0:
+                        bwd_op(op)
+            else:
+                for op in rev:
+                    yield [lambda op=op: bwd_op(op)]
+        lv[0] = None
         if deferred:            # (runs when the driver asks for the next step, outside any launch region)
             ops.wgrad_reduce_multi(deferred)
         return dx

@@ -35,6 +35,7 @@
  *      sums, the loss accumulators (chap_mix_loss_*: acc is a workspace of partial rows), chap_kl_fwd_bwd (ws),
  *      chap_channel_sum (ws), chap_l2_normalize (ws = N * CHAP_L2NORM_SLOTS floats) likewise.  chap_kl_fwd_bwd: `mode`
  *      (KL or Dice distance).  chap_grad_sim.
+ *   6  chap_capture_mark / chap_capture_goto / chap_capture_join: parallel branches of a captured graph on one stream
  *   5  chap_group_begin / chap_group_next_lane / chap_group_end: grouped launches of same-shaped layers (the two decoders of a
  *      DualDecoder, two passes of one network) -- one grid instead of 2-4, bit-identical results.
  */
@@ -48,7 +49,7 @@
 extern "C" {
 #endif
 
-#define CHAP_ABI_VERSION 5
+#define CHAP_ABI_VERSION 6
 #define CHAP_STATS_MAX_SLOTS 1024  /* per-block partial slots of the BatchNorm statistics (one per persistent conv block) */
 #define CHAP_STATS_HDR 4           /* floats in front of the slots; word 0 = number of slots in use (int32)                */
 #define CHAP_ACT_BWD_SLOTS 1024    /* per-block partial slots of the BN-backward sums                                      */
@@ -472,6 +473,24 @@ int chap_group_begin(void* stream);
 int chap_group_next_lane(void);
 int chap_group_end(void);
 int chap_group_cancel(void);   /* leave the region without issuing what was recorded (error paths of the caller) */
+
+/* ------------------------------------------------------------------------------------------
+ * Capture points (ABI 6): parallel branches of a captured HIP graph on ONE stream.  The reference gets no concurrency between its two
+ * decoders or between a layer's weight gradient and the rest of the backward chain (autograd issues them on one stream,
+ * train_ours_2D.py:386 `loss.backward()`); here the iteration is one HIP graph whose shape the caller controls.  A capturing stream
+ * has a dependency set -- the nodes the next captured launch depends on:
+ *     chap_capture_mark(stream, slot, accumulate)   slot := (accumulate ? slot U : ) dependency set of `stream`
+ *     chap_capture_goto(stream, slot)               dependency set := slot          (the next launches start a branch at the marked point)
+ *     chap_capture_join(stream, slot)               dependency set U= slot; the slot is released
+ * Two branches:   mark(F, 0); ...branch 1...; mark(T, 0); goto(F); ...branch 2...; join(T).
+ * A leaf off a chain (a weight gradient nobody needs before the optimizer step):
+ *                 mark(M, 0); ...leaf...; mark(LEAVES, 1); goto(M); ...the chain goes on...;   at the end   join(LEAVES).
+ * Return 1 when applied, 0 when `stream` is not capturing (nothing to do: stream order stands), negative CHAP_E* on error.  The CALLER
+ * must keep every buffer a branch touches alive (not hand it back to a stream-ordered allocator) until the join: inside the graph the
+ * branches run concurrently, whatever the order they were captured in.  Slots: 0 .. 15, thread-local, valid within one capture. */
+int chap_capture_mark(void* stream, int32_t slot, int32_t accumulate);
+int chap_capture_goto(void* stream, int32_t slot);
+int chap_capture_join(void* stream, int32_t slot);
 
 /* Bandwidth calibration helper (tools/membw.py): grid-stride float4 copy with `blocks` blocks of 256. */
 int chap_debug_copy(const void* src, void* dst, int64_t bytes, int32_t blocks, void* stream);

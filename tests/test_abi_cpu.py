@@ -29,10 +29,11 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 35
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.chap_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.chap_abi_version() == _lib.ABI_VERSION == 6
     # every entry point bound in the ctypes tables is declared in the header and vice versa
     bound = set(_lib._SIGS) | set(_lib._SIZE_FNS) | {"chap_last_error", "chap_abi_version", "chap_debug_copy", "chap_pack_describe", "chap_pack_multi",
-                                                                "chap_group_begin", "chap_group_next_lane", "chap_group_end", "chap_group_cancel", "chap_wgrad_reduce_multi"}
+                                                                "chap_group_begin", "chap_group_next_lane", "chap_group_end", "chap_group_cancel", "chap_wgrad_reduce_multi",
+                                                                "chap_capture_mark", "chap_capture_goto", "chap_capture_join"}
     assert bound == set(names), (bound ^ set(names))
 
 
@@ -238,3 +239,14 @@ def test_group_region_state_machine_without_a_gpu():
         g.next_lane()
         assert _lib.group.held == []
     assert _lib.group.held is None
+
+
+def test_capture_point_arguments():
+    """chap_capture_* (ABI 6): slots are 0 .. 15; the binding's regions leave no holder behind when they are not capturing."""
+    from chap_amd import _lib
+    lib = _lib.lib()
+    for fn, args in (("chap_capture_mark", (None, 16, 0)), ("chap_capture_goto", (None, -1)), ("chap_capture_join", (None, 99))):
+        f = getattr(lib, fn)
+        f.restype, f.argtypes = ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int32] * (len(args) - 1)
+        assert f(*args) < 0 and b"out of range" in lib.chap_last_error()
+    assert _lib._holders == []

@@ -356,3 +356,52 @@ def test_lockstep_schedule_equals_the_stream_parallel_schedule(dims):
     assert [k for k in sa if not torch.equal(sa[k], sb[k])] == []
     assert torch.equal(ma, mb)
     assert na > 100                                         # grouped regions really ran (and far more of them than in the stream-parallel schedule)
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_graph_branches_and_leaves_equal_the_default_graph(dims, monkeypatch):
+    """Round 3, ABI 6: with CHAP_GROUP=3 the decoders of a captured pass that cannot fork a stream are parallel BRANCHES of the graph on the
+    one stream, with CHAP_WGRAD_LEAF=1 the weight gradients are LEAVES off the backward chain (chap_capture_mark / _goto / _join).  Only the
+    shape of the graph changes -- same kernels, same operands -- so a replay equals the default graph's and the eager step BIT FOR BIT
+    (a missing dependency or a buffer recycled between concurrent branches would show here).  Measured slower: optional."""
+    from chap_amd import _lib as L
+    from chap_amd.networks import DualDecoder3d
+    from tests.iteration_parity import inject_2d, inject_3d, to_dev
+    if dims == 2:
+        B, lbs, sp = 8, 4, (64, 64)
+        state = oinit.dual_decoder_2d_state(301)
+        vol, lab = ots.synthetic_batch(1337, lbs, B - lbs, *sp)
+        inj = to_dev(inject_2d(B - lbs, lbs // 2 + (B - lbs) // 2, sp[0], sp[1], 1), 2)
+        mk, box, extra = (lambda: DualDecoder(1, 4, {"decoder_type": "mcnet"})), (7, 11), {}
+    else:
+        B, lbs, sp = 4, 2, (16, 32, 16)
+        state = oinit.dual_decoder_3d_state(401)
+        vol, lab = ots.synthetic_batch_3d(1337, lbs, B - lbs, *sp)
+        inj = to_dev(inject_3d(B - lbs, lbs // 2 + (B - lbs) // 2, sp, 1), 3)
+        mk, box, extra = (lambda: DualDecoder3d(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)), (2, 5, 3), {"num_classes": 2}
+    marks = []
+    real_mark = L.capture_mark
+    monkeypatch.setattr(L, "capture_mark", lambda *a, **k: (marks.append(1), real_mark(*a, **k))[1])
+    res = {}
+    for mode in ("eager", "graph", "dag"):
+        monkeypatch.setenv("CHAP_GROUP", "3" if mode == "dag" else "1")
+        monkeypatch.setenv("CHAP_WGRAD_LEAF", "1" if mode == "dag" else "0")
+        m = mk().to(DEV).train()
+        m.load_state_dict(state, strict=True)
+        step = ChapStep(m, dict(dict(labeled_bs=lbs, batch_size=B, vat_iters=1), **extra))
+        step.iter_num = 4500
+        n0 = len(marks)
+        if mode == "eager":
+            out = step.step(vol.to(DEV), lab.to(DEV), box_yx=box, inject=inj)
+        else:
+            step.capture(vol.to(DEV), lab.to(DEV), warmup=1, inject=inj)
+            out = step.replay(vol.to(DEV), lab.to(DEV), box_yx=box)
+        torch.cuda.synchronize()
+        res[mode] = (out, {k: v.clone() for k, v in m.state_dict().items()}, step.opt.mom.clone(), len(marks) - n0)
+    for mode in ("graph", "dag"):
+        (oa, sa, ma, _), (ob, sb, mb, nb) = res["eager"], res[mode]
+        for x, y in zip(oa["mix_losses"] + [oa["vat_loss"]], ob["mix_losses"] + [ob["vat_loss"]]):
+            assert torch.equal(x, y), (mode, x, y)
+        assert [k for k in sa if not torch.equal(sa[k], sb[k])] == [], mode
+        assert torch.equal(ma, mb), mode
+    assert res["graph"][3] == 0 and res["dag"][3] > 50      # the capture points were really used: two branch regions per forked pass, one leaf per weight gradient
