@@ -24,9 +24,12 @@ SEEDS = int(os.environ.get("CHAP_CONDITIONING_SEEDS", "3"))        # realisation
 
 
 # ------------------------------------------------------------------------------------------------ (1) small, ill-conditioned
-# default run: the default loop, K = 2 and the sign step; CHAP_CONDITIONING_ALL=1 adds the Dice distance and the combination (all five are in
-# profiles/r03_iteration_parity.jsonl) -- the -m gpu suite has to stay well inside the driver's time limit
-VARIANTS = ["base", "k2", "dice", "sign", "k2_dice_sign"] if os.environ.get("CHAP_CONDITIONING_ALL") == "1" else ["base", "k2", "sign"]
+# default run: the default loop and K = 2 (3D: K = 2, config 4's inner loop; K = 1 at this size is test_train_step_gpu's 3D case and config 3 below);
+# CHAP_CONDITIONING_ALL=1 adds the sign step, the Dice distance, their combination and 3D K = 1 (all of them are in
+# profiles/r03_iteration_parity.jsonl) -- the oracle legs run on the host, and the -m gpu suite has to stay well inside the driver's time limit
+# on a box with slow host cores too (measured 540 .. 700 s for the whole suite before this trim)
+ALL = os.environ.get("CHAP_CONDITIONING_ALL") == "1"
+VARIANTS = ["base", "k2", "dice", "sign", "k2_dice_sign"] if ALL else ["base", "k2"]
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -47,7 +50,7 @@ def test_small_2d_iteration_is_as_close_to_fp64_as_the_fp32_oracle(variant):
     assert_as_close_to_fp64_as_the_fp32_oracle(rms_over(runs), floors=dict(one_minus_cos=floor))
 
 
-@pytest.mark.parametrize("K", [1, 2])
+@pytest.mark.parametrize("K", [1, 2] if ALL else [2])
 def test_small_3d_iteration_is_as_close_to_fp64_as_the_fp32_oracle(K):
     B, lbs, sp = 4, 2, (16, 32, 16)
     U = B - lbs
