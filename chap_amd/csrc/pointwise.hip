@@ -508,21 +508,39 @@ __device__ __forceinline__ void upsample2x_bwd_kernel(const chap_upsample_bwd_pa
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
         // per-axis contributor lists first (the nested form evaluated the source coordinate 5*5*5 times per thread)
-        int oz_[5], oy_[5], ox_[5]; float wz_[5], wy_[5], wx_[5];
+        int oz_[5], oy_[5]; float wz_[5], wy_[5];
         int nz = 1; oz_[0] = z; wz_[0] = 1.f;
         if (P.dims == 3) nz = up_axis_adjoint(z, P.D, OD, oz_, wz_);
         const int ny = up_axis_adjoint(y, P.H, OH, oy_, wy_);
-        const int nx = up_axis_adjoint(x, P.W, OW, ox_, wx_);
-        for (int a = 0; a < nz; ++a)
-            for (int b = 0; b < ny; ++b)
-                for (int c = 0; c < nx; ++c) {
-                    const long fp = (((long)n * OD + oz_[a]) * OH + oy_[b]) * OW + ox_[c];
-                    float v[8];
-                    ld8(g + fp * P.g_ld + P.g_coff + c8, v);
-                    const float w = wz_[a] * wy_[b] * wx_[c];
+        // x: the FIXED window 2x-2 .. 2x+2, clamped, weight 0 where a sample does not touch x (or lies outside): the five loads of a
+        // (z, y) row are issued together instead of one dependent load per trip of a runtime-bounded loop (the kernel was load-latency
+        // bound: ~70 serial 16-byte loads per thread).  Contributions are added in the same ascending order as before, zero-weight
+        // ones skipped: bit-identical results.
+        int ox_[5]; float wx_[5];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, v[j], acc[j]);
+        for (int k = 0; k < 5; ++k) {
+            const int o = 2 * x - 2 + k, oc = min(max(o, 0), OW - 1);
+            int a0, a1; float w1;
+            ac_coord(oc, P.W, OW, a0, a1, w1);
+            const float w = (a0 == x ? 1.f - w1 : 0.f) + (a1 == x ? w1 : 0.f);
+            ox_[k] = oc; wx_[k] = (o == oc) ? w : 0.f;
+        }
+        for (int a = 0; a < nz; ++a)
+            for (int b = 0; b < ny; ++b) {
+                const long row = (((long)n * OD + oz_[a]) * OH + oy_[b]) * OW;
+                const float wzy = wz_[a] * wy_[b];
+                float v[5][8];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) ld8(g + (row + ox_[c]) * P.g_ld + P.g_coff + c8, v[c]);
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const float w = wzy * wx_[c];
+                    if (wx_[c] != 0.f) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(w, v[c][j], acc[j]);
+                    }
                 }
+            }
         const long cp = (((long)n * P.D + z) * P.H + y) * P.W + x;
         st8((T*)P.out + cp * P.C + c8, acc);
     }
