@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=5)       # ~13 s of CPU work at 2D config 1 (9.4 vol/s on 16 cores)
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs (config 3 = 3D bf16, and the 2D fp32 parity mode) of the default run")
     ap.add_argument("--extra-steps", type=int, default=10)
+    ap.add_argument("--stage", action="store_true", help="with --host-inputs: ChapStep.stage() the next batch beside the running iteration (what chap_amd's train() does)")
+    ap.add_argument("--host-inputs", choices=["pinned", "pageable"], default=None, help="hand every step HOST tensors (the reference's loader yields CPU batches): the "
+                    "PCIe-inclusive rate for DESIGN.md -- never the headline value, which is measured with the inputs resident in HBM")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="self-launched ranks (--gpus N without a launcher): overall limit in seconds")
     ap.add_argument("--rehearse-one-gpu", action="store_true", help="run the --gpus N ranks on cuda:0 together (1-GPU box), gradients all-reduced through host "
                     "memory over gloo: exercises the whole multi-rank path of this script end to end; the value is NOT a scaling measurement")
@@ -475,6 +478,18 @@ def main():
     if use_graph:
         step.capture(vol, lab, warmup=2)
         log("graph captured")
+    if args.host_inputs:
+        vol, lab = vol.cpu(), lab.cpu()
+        if args.host_inputs == "pinned":
+            vol, lab = vol.pin_memory(), lab.pin_memory()
+    if use_graph and args.stage and args.host_inputs:
+        step.stage(vol, lab)
+
+        def run():
+            out = step.replay()
+            step.stage(vol, lab)            # the next batch travels while this iteration runs
+            return out
+    elif use_graph:
         run = lambda: step.replay(vol, lab)                                    # noqa: E731
     else:
         run = lambda: step.step(vol, lab)                                      # noqa: E731
@@ -494,7 +509,8 @@ def main():
         roof["iteration_tflops"] = round(vps / world * flops_per_vol / 1e12, 2)
         line = {"metric": "training volumes/sec (%s)" % ("3D 112x112x80 bs4" if d3 else "2D 256^2 bs24"), "value": round(vps, 2), "unit": "volumes/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+                "data": "synthetic" if not args.host_inputs else "synthetic, handed over as %s HOST tensors every step (PCIe-inclusive: not the headline value)" % args.host_inputs,
                 "config": {"workload": workload_name(args.config, B, sp, K),
                            "global_batch": B * world, "parallelism": "dp%d" % world, "hip_graph": use_graph, "losses_finite": finite,
                            "grad_exchange": None if world == 1 and not force_dp else ("rccl all-reduce, bucket 0 overlapped with the VAT chain" if args.dp_overlap else "rccl all-reduce of the folded buckets")},

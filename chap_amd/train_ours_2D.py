@@ -70,16 +70,17 @@ def train(args, snapshot_path):
                 raise RuntimeError("chap_amd.train: the train loader yielded no batch (exhausted one-shot iterator or empty dataset) "
                                    "at iteration %d of %d" % (step.iter_num, a["max_iterations"]))
 
-    for sampled_batch in batches():
-        volume_batch = sampled_batch["image"].to(device, non_blocking=True)
-        label_batch = sampled_batch["label"].to(device, non_blocking=True)
+    gen = batches()
+    sampled_batch = next(gen)
+    while True:
         if a["use_graph"]:
             if not captured:
-                step.capture(volume_batch, label_batch)
+                step.capture(sampled_batch["image"].to(device), sampled_batch["label"].to(device))
                 captured = True
-            out = step.replay(volume_batch, label_batch)
+                step.stage(sampled_batch["image"], sampled_batch["label"])
+            out = step.replay()                      # the staged batch (host -> device copy done beside the previous iteration)
         else:
-            out = step.step(volume_batch, label_batch)
+            out = step.step(sampled_batch["image"].to(device, non_blocking=True), sampled_batch["label"].to(device, non_blocking=True))
         it = step.iter_num
         if it % 50 == 0:                                                         # (:404 logs every iteration: a host sync each)
             log.info("iteration %d : bcp loss : %f vat loss : %f" % (it, sum(float(l[2]) for l in out["mix_losses"]), float(out["vat_loss"])))
@@ -98,6 +99,9 @@ def train(args, snapshot_path):
             model.train()
         if it >= a["max_iterations"]:
             break
+        sampled_batch = next(gen)
+        if a["use_graph"]:
+            step.stage(sampled_batch["image"], sampled_batch["label"])      # travels while the iteration enqueued above runs
     log.removeHandler(fh)
     fh.close()
     return model

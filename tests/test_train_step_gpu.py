@@ -405,3 +405,39 @@ def test_graph_branches_and_leaves_equal_the_default_graph(dims, monkeypatch):
         assert [k for k in sa if not torch.equal(sa[k], sb[k])] == [], mode
         assert torch.equal(ma, mb), mode
     assert res["graph"][3] == 0 and res["dag"][3] > 50      # the capture points were really used: two branch regions per forked pass, one leaf per weight gradient
+
+
+def test_staged_host_batches_equal_direct_replay():
+    """ChapStep.stage() + replay() (the next batch's host-to-device copy on a copy stream beside the running iteration, what train() does) against
+    replay(volume, label) with device tensors: three iterations on three different batches, bit for bit -- the hand-over between the copy stream,
+    the staging buffers and the graph's static inputs loses or reorders nothing."""
+    B, lbs, sp = 8, 4, (64, 64)
+    state = oinit.dual_decoder_2d_state(301)
+    batches = [ots.synthetic_batch(1337 + k, lbs, B - lbs, *sp) for k in range(3)]
+    res = {}
+    for mode in ("direct", "staged"):
+        m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train()
+        m.load_state_dict(state, strict=True)
+        step = ChapStep(m, dict(labeled_bs=lbs, batch_size=B, vat_iters=1))
+        step.capture(batches[0][0].to(DEV), batches[0][1].to(DEV), warmup=1)
+        outs = []
+        if mode == "staged":
+            pinned = [(v.pin_memory(), l.pin_memory()) for v, l in batches]
+            step.stage(*pinned[0])
+            for k in range(3):
+                out = step.replay(box_yx=(7, 11))
+                if k + 1 < 3:
+                    step.stage(*pinned[k + 1])          # enqueued while iteration k runs
+                outs.append([x.clone() for x in out["mix_losses"]] + [out["vat_loss"].clone()])
+            with pytest.raises(RuntimeError, match="stage"):
+                step.replay()                           # nothing staged
+        else:
+            for k in range(3):
+                out = step.replay(batches[k][0].to(DEV), batches[k][1].to(DEV), box_yx=(7, 11))
+                outs.append([x.clone() for x in out["mix_losses"]] + [out["vat_loss"].clone()])
+        torch.cuda.synchronize()
+        res[mode] = (outs, {k: v.clone() for k, v in m.state_dict().items()})
+    for a, b in zip(res["direct"][0], res["staged"][0]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert [k for k in res["direct"][1] if not torch.equal(res["direct"][1][k], res["staged"][1][k])] == []
