@@ -1,5 +1,7 @@
 #!/bin/bash
-# Round 3: launch share (chap_set_launch_share) of pass B / the early VAT pass -- the passes with slack beside the iteration's long chain
+# Round 3: launch share (chap_set_launch_share) of pass B / the early VAT pass -- the passes with slack beside the iteration's long chain.
+# HISTORICAL: the knobs CHAP_SHARE_B / CHAP_SHARE_PRE and the entry point existed only for this A/B (commit 0570834 removed them again: measured flat,
+# profiles/r03_launch_share_ab.log); the script is kept as the record of what was run.
 set -o pipefail
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/sh; mkdir -p $O; cd $R
 b() { tag=$1; shift
