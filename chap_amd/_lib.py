@@ -54,23 +54,12 @@ class ConvC1BwdParams(C.Structure):
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("dims", _i32), ("Cout", _i32), ("dtype", _i32)]
 
 
-class Bgrad(C.Structure):
-    _fields_ = [("dy", _vp), ("dy_ld", _i32), ("dy_coff", _i32), ("sums", _vp), ("mean", _vp), ("invstd", _vp), ("gamma", _vp),
-                ("count", _f32), ("gout", _vp)]
-
-
-class WgradReduceEntry(C.Structure):
-    _fields_ = [("ws", _vp), ("ws_db", _vp), ("dw", _vp), ("db", _vp), ("s_tap", _i64), ("s_kc", _i64), ("s_kn", _i64),
-                ("nsplit", _i32), ("taps", _i32), ("Ca", _i32), ("Cb", _i32), ("kc_valid", _i32), ("kn_valid", _i32),
-                ("nb_dw", _i32), ("nblocks", _i32), ("e4", _i32)]
-
-
 class WgradParams(C.Structure):
     _fields_ = [("a", Src * 2), ("na", _i32), ("combine", _i32), ("b", Src),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("ID", _i32), ("IH", _i32), ("IW", _i32),
                 ("ksize", _i32), ("stride", _i32), ("dims", _i32),
                 ("dw", _vp), ("s_tap", _i64), ("s_kc", _i64), ("s_kn", _i64), ("kc_valid", _i32), ("kn_valid", _i32),
-                ("db", _vp), ("ws", _vp), ("ws_bytes", _sz), ("dtype", _i32), ("bgrad", Bgrad), ("deferred", C.POINTER(WgradReduceEntry))]
+                ("db", _vp), ("ws", _vp), ("ws_bytes", _sz), ("dtype", _i32)]
 
 
 class BnFinalizeParams(C.Structure):
@@ -230,7 +219,7 @@ _SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParam
 _lib = None
 
 
-ABI_VERSION = 6            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
+ABI_VERSION = 7            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
 
 
 class ChapError(RuntimeError):
@@ -294,20 +283,6 @@ def pack_describe(params):
     return e
 
 
-def wgrad_reduce_multi(entries, stream):
-    """chap_wgrad_reduce_multi: the slab reductions of the weight gradients recorded in `entries` (WgradReduceEntry objects that
-    chap_wgrad filled), up to 16 layers per launch."""
-    if not entries:
-        return
-    L = lib()
-    L.chap_wgrad_reduce_multi.restype = C.c_int
-    L.chap_wgrad_reduce_multi.argtypes = [C.POINTER(WgradReduceEntry), _i32, _vp]
-    arr = (WgradReduceEntry * len(entries))(*entries)
-    rc = L.chap_wgrad_reduce_multi(arr, len(entries), _vp(stream))
-    if rc != 0:
-        raise ChapError("chap_wgrad_reduce_multi failed (%d): %s" % (rc, L.chap_last_error().decode()))
-
-
 def pack_multi(entries_dev_ptr, n, max_total, stream):
     L = lib()
     L.chap_pack_multi.restype = C.c_int
@@ -317,7 +292,7 @@ def pack_multi(entries_dev_ptr, n, max_total, stream):
         raise ChapError("chap_pack_multi failed (%d): %s" % (rc, L.chap_last_error().decode()))
 
 
-_holders = []       # the `held` lists of the open regions (group / branches / leaves), see hold()
+_holders = []       # the `held` lists of the open group regions, see hold()
 
 
 def _drop_holder(h):
@@ -370,122 +345,13 @@ class group:
         return False
 
 
-def _capture_call(name, stream, *rest):
-    L = lib()
-    fn = getattr(L, name)
-    fn.restype, fn.argtypes = C.c_int, [_vp] + [C.c_int32] * len(rest)
-    rc = fn(_vp(stream), *rest)
-    if rc < 0:
-        raise ChapError("%s failed (%d): %s" % (name, rc, L.chap_last_error().decode()))
-    return rc == 1
-
-
-def capture_mark(stream, slot, accumulate=False):
-    """chap_capture_mark: slot := (slot U) the capture dependency set of `stream`.  True when applied, False when not capturing."""
-    return _capture_call("chap_capture_mark", stream, slot, 1 if accumulate else 0)
-
-
-def capture_goto(stream, slot):
-    return _capture_call("chap_capture_goto", stream, slot)
-
-
-def capture_join(stream, slot):
-    return _capture_call("chap_capture_join", stream, slot)
-
-
-# capture-point slots used by this package (chap_hip.h: 0 .. 15, thread-local)
-SLOT_FORK, SLOT_TAIL, SLOT_LEAF_AT, SLOT_LEAVES = 0, 1, 2, 3
-
-
-class branches:
-    """`with branches(stream) as b: ...branch 1...; b.next(); ...branch 2...`: under a graph capture the two parts become PARALLEL
-    branches of the graph on the one stream (chap_capture_mark / _goto / _join); otherwise they simply run one after the other.
-    Everything allocated through hold() inside is kept alive until the join: the branches run concurrently in the graph whatever the
-    order they were captured in, so a buffer that branch 1 released must not be handed to branch 2 by the stream-ordered allocator."""
-    def __init__(self, stream, fork=SLOT_FORK, tail=SLOT_TAIL):
-        self.stream, self.fork, self.tail = stream, fork, tail
-        self.active = self.tails = False
-        self.held = []
-
-    def __enter__(self):
-        self.active = capture_mark(self.stream, self.fork)
-        if self.active:
-            _holders.append(self.held)
-        return self
-
-    def next(self):
-        if self.active:
-            capture_mark(self.stream, self.tail, accumulate=self.tails)
-            self.tails = True
-            capture_goto(self.stream, self.fork)
-
-    def __exit__(self, et, ev, tb):
-        if self.active:
-            try:
-                if et is None and self.tails:
-                    capture_join(self.stream, self.tail)
-            finally:
-                _drop_holder(self.held)
-                self.held = []
-        return False
-
-
-class leaves:
-    """Leaves off a chain under a graph capture: `with leaves(stream) as lv: ... with lv.leaf(): <launches nobody on the chain waits
-    for> ...`: the launches inside leaf() depend on what the chain had issued up to there, the chain goes on without them, and everything
-    meets again when the region ends.  Buffers allocated through hold() anywhere inside the region are kept until then.  Outside a
-    capture: plain stream order."""
-    def __init__(self, stream, at=SLOT_LEAF_AT, acc=SLOT_LEAVES, enabled=True):
-        self.stream, self.at, self.acc, self.enabled = stream, at, acc, enabled
-        self.active = self.any = False
-        self.held = []
-
-    def __enter__(self):
-        if self.enabled:
-            self.active = capture_mark(self.stream, self.at)
-            if self.active:
-                _holders.append(self.held)
-        return self
-
-    def leaf(self):
-        return _leaf(self)
-
-    def __exit__(self, et, ev, tb):
-        if self.active:
-            try:
-                if et is None and self.any:
-                    capture_join(self.stream, self.acc)
-            finally:
-                _drop_holder(self.held)
-                self.held = []
-        return False
-
-
-class _leaf:
-    def __init__(self, region):
-        self.r = region
-
-    def __enter__(self):
-        if self.r.active:
-            capture_mark(self.r.stream, self.r.at)
-        return self
-
-    def __exit__(self, et, ev, tb):
-        r = self.r
-        if r.active and et is None:
-            capture_mark(r.stream, r.acc, accumulate=r.any)
-            r.any = True
-            capture_goto(r.stream, r.at)
-        return False
-
-
 def hold(t):
     """Inside a group region the lanes' kernels run CONCURRENTLY, later than the Python code that allocated their buffers: a
     temporary that Python drops (a workspace local to a wrapper, a gradient tensor consumed by the launches of its op) would go
     back to the caching allocator and could be handed to the NEXT lane of the same region -- two lanes of one grid writing the
     same memory.  Every tensor allocated on this path goes through hold(): kept alive until chap_group_end has issued the launches
     (stream order protects it from then on).  No-op outside a region."""
-    for h in _holders:                      # (group regions; parallel graph branches / leaves on one stream: same reason, until the join)
+    for h in _holders:
         h.append(t)
     return t
 

@@ -20,7 +20,6 @@ static int kpar_launch(const chap_conv_params* p, hipStream_t stream) {
     const long ntiles = (long)p->N * p->D * cdiv(p->H, G::TH) * cdiv(p->W, G::TW);
     const long gx = ntiles < CHAP_STATS_MAX_SLOTS ? ntiles : CHAP_STATS_MAX_SLOTS;      // one statistics slot per block (chap_hip.h)
     const int gy = cdiv((p->Cout + 15) / 16, NT);
-    if (p->stats) chap_note_stats_slots(p->stats, (int)gx);
     return chap_launch_ptr<chap_conv_params>(kern, dim3((unsigned)gx, gy), dim3(256), lds, stream, *p, "chap_conv_fwd(kpar)");
 }
 

@@ -80,69 +80,3 @@ extern "C" int chap_group_cancel(void) {
     G.lanes.clear();
     return CHAP_OK;
 }
-
-namespace { thread_local const float* g_stats_ptr = nullptr; thread_local int g_stats_slots = 0; }
-void chap_note_stats_slots(const float* stats, int slots) { g_stats_ptr = stats; g_stats_slots = slots; }
-int chap_known_stats_slots(const float* stats) {      // one-shot: only the finalize call right behind the conv may use the note
-    const int n = (stats != nullptr && stats == g_stats_ptr) ? g_stats_slots : 0;
-    g_stats_ptr = nullptr;
-    return n;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Capture points (chap_hip.h, chap_capture_*): parallel branches of a captured HIP graph on ONE stream.  A capturing stream has a
-// "dependency set": the graph nodes the next captured launch will depend on.  Saving that set (mark), restoring it (goto) and adding a
-// saved set back (join) forks and joins branches without a second stream and without events -- which matters on ROCm 7.2, where an
-// event dependency between two streams that were both forked from the capture's origin crashes hipStreamEndCapture, so a pass that
-// already runs on a forked stream could not fork again.  Outside a capture the three calls do nothing (stream order stands).
-namespace {
-constexpr int CAP_SLOTS = 16;
-struct cap_slot { unsigned long long id = 0; std::vector<hipGraphNode_t> nodes; bool set = false; };
-thread_local cap_slot g_cap[CAP_SLOTS];
-
-// 1 = capturing (deps filled), 0 = not capturing, < 0 error
-int capture_deps(hipStream_t s, const char* who, unsigned long long* id, std::vector<hipGraphNode_t>* deps) {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    hipGraph_t g = nullptr;
-    const hipGraphNode_t* d = nullptr;
-    size_t n = 0;
-    const hipError_t e = hipStreamGetCaptureInfo_v2(s, &st, id, &g, &d, &n);
-    if (e != hipSuccess) { (void)hipGetLastError(); chap_set_error("%s: hipStreamGetCaptureInfo_v2 failed: %s", who, hipGetErrorString(e)); return CHAP_ELAUNCH; }
-    if (st != hipStreamCaptureStatusActive) return 0;
-    if (deps) deps->assign(d, d + n);
-    return 1;
-}
-}  // namespace
-
-extern "C" int chap_capture_mark(void* stream, int slot, int accumulate) {
-    CHAP_CHECK_ARG(slot >= 0 && slot < CAP_SLOTS, "chap_capture_mark: slot %d out of range [0, %d)", slot, CAP_SLOTS);
-    CHAP_NOT_IN_GROUP("chap_capture_mark");
-    unsigned long long id = 0;
-    std::vector<hipGraphNode_t> deps;
-    const int rc = capture_deps((hipStream_t)stream, "chap_capture_mark", &id, &deps);
-    if (rc <= 0) return rc;
-    cap_slot& c = g_cap[slot];
-    if (!accumulate || !c.set || c.id != id) { c.nodes.clear(); c.id = id; c.set = true; }
-    for (hipGraphNode_t nd : deps) {
-        bool have = false;
-        for (hipGraphNode_t o : c.nodes) have = have || o == nd;
-        if (!have) c.nodes.push_back(nd);
-    }
-    return 1;
-}
-
-static int capture_update(void* stream, int slot, unsigned flags, bool clear, const char* who) {
-    CHAP_CHECK_ARG(slot >= 0 && slot < CAP_SLOTS, "%s: slot %d out of range [0, %d)", who, slot, CAP_SLOTS);
-    CHAP_NOT_IN_GROUP(who);
-    unsigned long long id = 0;
-    const int rc = capture_deps((hipStream_t)stream, who, &id, nullptr);
-    if (rc <= 0) return rc;
-    cap_slot& c = g_cap[slot];
-    if (!c.set || c.id != id) { chap_set_error("%s: slot %d was not marked in this capture", who, slot); return CHAP_EINVAL; }
-    const hipError_t e = hipStreamUpdateCaptureDependencies((hipStream_t)stream, c.nodes.data(), c.nodes.size(), flags);
-    if (e != hipSuccess) { (void)hipGetLastError(); chap_set_error("%s: hipStreamUpdateCaptureDependencies failed: %s", who, hipGetErrorString(e)); return CHAP_ELAUNCH; }
-    if (clear) { c.nodes.clear(); c.set = false; }
-    return 1;
-}
-extern "C" int chap_capture_goto(void* stream, int slot) { return capture_update(stream, slot, hipStreamSetCaptureDependencies, false, "chap_capture_goto"); }
-extern "C" int chap_capture_join(void* stream, int slot) { return capture_update(stream, slot, hipStreamAddCaptureDependencies, true, "chap_capture_join"); }

@@ -75,12 +75,6 @@ static int chap_launch_z(dim3 grid, dim3 block, size_t lds, hipStream_t s, const
     return chap_launch_ptr<A>((const void*)chap_grouped_z<A, BODY, MAXT, MINW>, grid, block, lds, s, a, name);
 }
 
-// The number of statistics slots (= grid.x) of the conv launch that last wrote a given statistics buffer, remembered per host thread so that
-// chap_bn_finalize -- called right behind it -- can pass the count as a kernel argument instead of loading the header word first (one
-// dependent memory round trip of a kernel that is nothing but latency).  0 = unknown (the kernel reads the header).
-void chap_note_stats_slots(const float* stats, int slots);
-int chap_known_stats_slots(const float* stats);
-
 // entry points whose kernels are launched directly (not through chap_launch) must not be called inside a group region: their
 // launch would overtake the recorded ones
 #define CHAP_NOT_IN_GROUP(name) do { if (chap_group_recording()) { chap_set_error("%s: not allowed between chap_group_begin() and chap_group_end()", name); return CHAP_EUNSUPPORTED; } } while (0)

@@ -84,7 +84,6 @@ extern "C" int chap_conv_c1_fwd(const chap_conv_c1_params* p, void* stream) {
     dim3 grid((unsigned)(cdiv(npix, 256) < CHAP_STATS_MAX_SLOTS ? cdiv(npix, 256) : CHAP_STATS_MAX_SLOTS));   // one statistics slot per block
     hipStream_t s = (hipStream_t)stream;
     const bool d3 = p->dims == 3, bf = p->dtype == CHAP_BF16;
-    if (p->stats) chap_note_stats_slots(p->stats, (int)grid.x);
     if (bf && d3) return chap_launch<chap_conv_c1_params, conv_c1_fwd_kernel<bf16_t, true, 16>, 256>(grid, dim3(256), 0, s, *p, "chap_conv_c1_fwd");
     if (bf) return chap_launch<chap_conv_c1_params, conv_c1_fwd_kernel<bf16_t, false, 16>, 256>(grid, dim3(256), 0, s, *p, "chap_conv_c1_fwd");
     if (d3) return chap_launch<chap_conv_c1_params, conv_c1_fwd_kernel<float, true, 16>, 256>(grid, dim3(256), 0, s, *p, "chap_conv_c1_fwd");
@@ -236,12 +235,12 @@ extern "C" int chap_conv_c1_bwd(const chap_conv_c1_bwd_params* p, void* stream) 
 // One wave per channel: lane l sums slots l, l+64, ... (and the sub-lattice rows of a transposed conv) in fp64, then a
 // fixed xor butterfly -- the same order on every run.  mean = c + S/n, var = Q/n - (S/n)^2 with the moments taken about
 // the conv's shift c (no cancellation once c tracks the mean), evaluated in fp64.
-struct bn_finalize_args { chap_bn_finalize_params P; int nslots; };      // nslots: from the host when it knows the conv's grid (launch.h), else 0
-__device__ __forceinline__ void bn_finalize_kernel(const bn_finalize_args& A) {
-    const chap_bn_finalize_params& P = A.P;
+__device__ __forceinline__ void bn_finalize_kernel(const chap_bn_finalize_params& P) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= P.C) return;
-    const int nslots = A.nslots > 0 ? A.nslots : *(const int*)P.stats;
+    // slots in use: the header word the producing conv wrote (a host-side note of the conv's grid was tried in round 3 to save this
+    // load: no measurable difference, and a hidden coupling between two calls -- removed)
+    const int nslots = *(const int*)P.stats;
     // the per-channel parameters are requested NOW, next to the header and the slots: behind the reduction they were a third
     // dependent memory round trip of a kernel that is nothing but latency
     const bool upd = P.momentum > 0.f && P.running_mean;
@@ -290,11 +289,10 @@ __device__ __forceinline__ void bn_finalize_kernel(const bn_finalize_args& A) {
 extern "C" int chap_bn_finalize(const chap_bn_finalize_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->stats && p->gamma && p->beta && p->scale && p->shift && p->C > 0 && p->count > 0, "chap_bn_finalize: bad argument");
     CHAP_CHECK_ARG(p->Clog >= p->C && p->Clog % p->C == 0, "chap_bn_finalize: Clog=%d must be a multiple of C=%d", p->Clog, p->C);
-    { static int skip = -1; if (skip < 0) skip = getenv("CHAP_LAB_SKIP_BNFIN") ? 1 : 0; if (skip) return CHAP_OK; }      // lab: timing bound only (wrong numerics)
-    static int use_known = -1;
-    if (use_known < 0) { const char* e = getenv("CHAP_BNFIN_KNOWN_SLOTS"); use_known = (e && atoi(e) == 0) ? 0 : 1; }      // lab knob
-    const bn_finalize_args a = {*p, use_known ? chap_known_stats_slots(p->stats) : 0};
-    return chap_launch<bn_finalize_args, bn_finalize_kernel, 256>(dim3(cdiv(p->C, 4)), dim3(256), 0, (hipStream_t)stream, a, "chap_bn_finalize");
+#ifdef CHAP_LAB      // lab builds only (tools/lab, loaded through CHAP_LIBPATH): timing bound, wrong numerics
+    { static int skip = -1; if (skip < 0) skip = getenv("CHAP_LAB_SKIP_BNFIN") ? 1 : 0; if (skip) return CHAP_OK; }
+#endif
+    return chap_launch<chap_bn_finalize_params, bn_finalize_kernel, 256>(dim3(cdiv(p->C, 4)), dim3(256), 0, (hipStream_t)stream, *p, "chap_bn_finalize");
 }
 
 __device__ __forceinline__ void bn_eval_kernel(const chap_bn_eval_params& P) {
@@ -599,15 +597,9 @@ __device__ __forceinline__ void act_bwd_dz(const chap_act_bwd_params& P, const f
     }
 }
 
-// nrows (apply phase): > 0 = total the first `nrows` partial rows of the reduce phase HERE, in every block (fixed order, fp64), and let
-// block 0 add the BatchNorm parameter gradients (CHAP_ACTBWD_FOLD=1, lab: measured slower, see act_bwd_fold); 0 (default) = row 0
-// holds the totals, act_bwd_sum_kernel ran.
-struct act_bwd_args { chap_act_bwd_params P; int nrows; };
-
 template <typename T, bool APPLY>
-__device__ __forceinline__ void act_bwd_kernel(const act_bwd_args& A) {
-    const chap_act_bwd_params& P = A.P;
-    extern __shared__ float red[];            // reduce phase: [4 waves][2][C] partials; apply phase: [2][C] totals (+ [256 | 2C] fp64 lane partials)
+__device__ __forceinline__ void act_bwd_kernel(const chap_act_bwd_params& P) {
+    extern __shared__ float red[];            // reduce phase: [4 waves][2][C] partials; apply phase: [2][C] totals
     const int C = P.r.C, C8 = C / 8;
     const long npix = (long)P.N * P.D * P.H * P.W;
     const int c8 = (threadIdx.x % C8) * 8;
@@ -622,49 +614,9 @@ __device__ __forceinline__ void act_bwd_kernel(const act_bwd_args& A) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) { cB[j] = 0.f; cC[j] = 0.f; cM[j] = -mean[j] * istd[j]; }      // xhat = raw*istd + cM
     if (APPLY) {
-        if (A.nrows > 0) {
-            // totals of the reduce phase's partial rows: value v = (which, channel), rows rl, rl + nrl, ... per thread with 8 loads in
-            // flight, the nrl lane partials of a value joined in a fixed order -- every block computes the same bits
-            const int V = 2 * C, nrows = A.nrows;
-            double* comb = (double*)(red + V);
-            const float* src = P.sums + V;             // row 1 = the first partial row
-            if (V <= 256) {
-                const int v = threadIdx.x % V, rl = threadIdx.x / V, nrl = 256 / V;
-                double t = 0.0;
-                int r = rl;
-                for (; r + 7 * nrl < nrows; r += 8 * nrl) {
-                    float x[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) x[k] = src[(long)(r + k * nrl) * V + v];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) t += (double)x[k];
-                }
-                for (; r < nrows; r += nrl) t += (double)src[(long)r * V + v];
-                comb[rl * V + v] = t;
-                __syncthreads();
-                if ((int)threadIdx.x < V) {
-                    double a = 0.0;
-                    for (int k = 0; k < nrl; ++k) a += comb[k * V + threadIdx.x];
-                    red[threadIdx.x] = (float)a;
-                }
-            } else {
-                for (int v = threadIdx.x; v < V; v += 256) {
-                    double t = 0.0;
-                    for (int r = 0; r < nrows; ++r) t += (double)src[(long)r * V + v];
-                    red[v] = (float)t;
-                }
-            }
-            __syncthreads();
-            if (blockIdx.x == 0)                       // BatchNorm parameter gradients: one writer per layer
-                for (int i = threadIdx.x; i < V; i += 256) {
-                    if (i < C) { if (P.dbeta) P.dbeta[i] += red[i]; } else if (P.dgamma) P.dgamma[i - C] += red[i];
-                }
-        }
         if (P.bn == 1) {                               // training-mode BatchNorm backward
-            if (A.nrows <= 0) {                        // totals in row 0 (written by act_bwd_sum_kernel together with dgamma / dbeta)
-                for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = P.sums[i];
-                __syncthreads();
-            }
+            for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = P.sums[i];      // totals in row 0 (written by act_bwd_sum_kernel together with dgamma / dbeta)
+            __syncthreads();
             float gm[8], a0[8], a1[8];
             ld8(P.gamma + c8, gm);
 #pragma unroll
@@ -762,24 +714,8 @@ static int act_bwd_check(const chap_act_bwd_params* p) {
     CHAP_CHECK_ARG(!p->g_pool || (p->pool_idx && p->D == 1 && p->H % 2 == 0 && p->W % 2 == 0), "chap_act_bwd: pooled gradient needs idx and even 2D dims");
     return CHAP_OK;
 }
-// CHAP_ACTBWD_FOLD=1 (lab; default 0): the apply phase totals the partial rows itself instead of the one-wave-per-value totals kernel.
-// Measured on the whole iteration (round 3, on-box A/B x2): 2D 6.77 -> 6.95 ms, 3D 14.91 -> 15.04 ms per step -- every apply block
-// re-reading up to 64 KB of rows costs more than the 78 / 126 launches it saves.  Kept off.
-static int act_bwd_fold() {
-    static int f = -1;
-    if (f < 0) { const char* e = getenv("CHAP_ACTBWD_FOLD"); f = (e && atoi(e) == 1) ? 1 : 0; }
-    return f;
-}
-static int act_bwd_blocks(const chap_act_bwd_params* p);
-// partial rows of the reduce phase = its grid.  With the totals folded into the apply phase every apply block reads all rows, so their
-// number is bounded by the volume: rows x 2C floats <= 64 KB (C = 16: 512 rows, C = 256: 32 -- the wide layers are small tensors).
-static int act_bwd_rows(const chap_act_bwd_params* p) {
-    const int b = act_bwd_blocks(p);
-    if (!act_bwd_fold()) return b;
-    int cap = 8192 / p->r.C;
-    if (cap < 8) cap = 8;
-    return b < cap ? b : cap;
-}
+// (Round 3 measured the totals folded into the apply phase -- every apply block re-reading the partial rows instead of the totals kernel:
+// 2D 6.77 -> 6.95 ms, 3D 14.91 -> 15.04 ms per step, slower; removed in round 4, the record is in DESIGN.md section 5.)
 static int act_bwd_blocks(const chap_act_bwd_params* p) {
     const long npix = (long)p->N * p->D * p->H * p->W;
     const int ppb = 256 / (p->r.C / 8);
@@ -795,30 +731,25 @@ extern "C" int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream) {
     int r = act_bwd_check(p); if (r) return r;
     CHAP_CHECK_ARG(p->bn && p->mean && p->invstd && p->sums, "chap_act_bwd_reduce: needs bn, mean, invstd, sums");
     const size_t lds = 4 * 2 * p->r.C * sizeof(float);
-    const int nb = act_bwd_rows(p);
-    const act_bwd_args a = {*p, 0};
-    if (p->dtype == CHAP_BF16) r = chap_launch<act_bwd_args, act_bwd_kernel<bf16_t, false>, 256>(dim3(nb), dim3(256), lds, (hipStream_t)stream, a, "chap_act_bwd_reduce");
-    else r = chap_launch<act_bwd_args, act_bwd_kernel<float, false>, 256>(dim3(nb), dim3(256), lds, (hipStream_t)stream, a, "chap_act_bwd_reduce");
+    const int nb = act_bwd_blocks(p);              // one partial row per block
+    if (p->dtype == CHAP_BF16) r = chap_launch<chap_act_bwd_params, act_bwd_kernel<bf16_t, false>, 256>(dim3(nb), dim3(256), lds, (hipStream_t)stream, *p, "chap_act_bwd_reduce");
+    else r = chap_launch<chap_act_bwd_params, act_bwd_kernel<float, false>, 256>(dim3(nb), dim3(256), lds, (hipStream_t)stream, *p, "chap_act_bwd_reduce");
     if (r) return r;
-    if (act_bwd_fold()) return CHAP_OK;            // chap_act_bwd_apply totals the rows
-    { static int skip = -1; if (skip < 0) skip = getenv("CHAP_LAB_SKIP_ACTSUM") ? 1 : 0; if (skip) return CHAP_OK; }     // lab: timing bound only (wrong numerics)
+#ifdef CHAP_LAB      // lab builds only: timing bound, wrong numerics
+    { static int skip = -1; if (skip < 0) skip = getenv("CHAP_LAB_SKIP_ACTSUM") ? 1 : 0; if (skip) return CHAP_OK; }
+#endif
     const act_bwd_sum_args sa = {p->sums, nb, p->dgamma, p->dbeta, p->r.C};
     return chap_launch<act_bwd_sum_args, act_bwd_sum_kernel, 256>(dim3(cdiv(2 * p->r.C, 4)), dim3(256), 0, (hipStream_t)stream, sa, "chap_act_bwd_reduce(sum)");
 }
 extern "C" int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream) {
     int r = act_bwd_check(p); if (r) return r;
     CHAP_CHECK_ARG(p->gout, "chap_act_bwd_apply: null gout");
-    // lab: timing bound only (wrong numerics) for folding this pass into the loads of the dgrad / weight-gradient kernels ("lazy gradient"):
-    // with the launch and its bytes gone and NOTHING added to the consumers, the step is the floor of what that fusion could reach
+#ifdef CHAP_LAB      // lab builds only: timing bound (wrong numerics) for folding this pass into the loads of its consumers
     { static int skip = -1; if (skip < 0) skip = getenv("CHAP_LAB_SKIP_ACTAPPLY") ? 1 : 0; if (skip && p->bn == 1) return CHAP_OK; }
-    // the reduce phase ran iff the caller needed sums (training-mode BatchNorm, or BatchNorm parameter gradients of an eval-mode one)
-    const bool reduced = p->sums != nullptr && (p->bn == 1 || (p->bn == 2 && (p->dgamma || p->dbeta)));
-    const int nrows = (reduced && act_bwd_fold()) ? act_bwd_rows(p) : 0;
-    const int V = 2 * p->r.C;
-    const size_t lds = V * sizeof(float) + (nrows > 0 ? (size_t)(V <= 256 ? 256 : 0) * sizeof(double) : 0);
-    const act_bwd_args a = {*p, nrows};
-    if (p->dtype == CHAP_BF16) return chap_launch<act_bwd_args, act_bwd_kernel<bf16_t, true>, 256>(dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, a, "chap_act_bwd_apply");
-    return chap_launch<act_bwd_args, act_bwd_kernel<float, true>, 256>(dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, a, "chap_act_bwd_apply");
+#endif
+    const size_t lds = 2 * p->r.C * sizeof(float);
+    if (p->dtype == CHAP_BF16) return chap_launch<chap_act_bwd_params, act_bwd_kernel<bf16_t, true>, 256>(dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p, "chap_act_bwd_apply");
+    return chap_launch<chap_act_bwd_params, act_bwd_kernel<float, true>, 256>(dim3(act_bwd_blocks(p)), dim3(256), lds, (hipStream_t)stream, *p, "chap_act_bwd_apply");
 }
 
 // =========================================================================================

@@ -88,7 +88,8 @@ extern "C" size_t chap_wgrad_ws(const chap_wgrad_params* p) {
 // Blocks [0, nb_dw) reduce dW, blocks [nb_dw, ...) reduce the bias-gradient partials the same way.
 struct wgrad_reduce_args { const float* ws; const float* ws_db; int nsplit, taps, Ca, Cb; float* dw; long s_tap, s_kc, s_kn; int kc_valid, kn_valid; float* db; int nb_dw; };
 template <int E4>
-__device__ __forceinline__ void wgrad_reduce_body(const wgrad_reduce_args& A, const int bid) {
+__device__ __forceinline__ void wgrad_reduce_kernel(const wgrad_reduce_args& A) {
+    const int bid = (int)blockIdx.x;
     const float* __restrict__ ws = A.ws; const float* __restrict__ ws_db = A.ws_db;
     const int nsplit = A.nsplit, taps = A.taps, Ca = A.Ca, Cb = A.Cb, kc_valid = A.kc_valid, kn_valid = A.kn_valid, nb_dw = A.nb_dw;
     float* dw = A.dw; float* db = A.db;
@@ -130,43 +131,6 @@ __device__ __forceinline__ void wgrad_reduce_body(const wgrad_reduce_args& A, co
     }
 }
 
-template <int E4>
-__device__ __forceinline__ void wgrad_reduce_kernel(const wgrad_reduce_args& A) { wgrad_reduce_body<E4>(A, (int)blockIdx.x); }
-
-// the reductions of up to WG_MULTI layers in one grid: block -> (entry, block of that entry's own reduction grid)
-constexpr int WG_MULTI = 16;
-struct wgrad_reduce_multi_args { wgrad_reduce_args e[WG_MULTI]; int e4[WG_MULTI]; int first[WG_MULTI + 1]; int n; };
-__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(const wgrad_reduce_multi_args M) {
-    int j = 0;
-    while (j + 1 < M.n && (int)blockIdx.x >= M.first[j + 1]) ++j;          // uniform scan over <= 16 offsets
-    const int bid = (int)blockIdx.x - M.first[j];
-    if (M.e4[j] == 8) wgrad_reduce_body<8>(M.e[j], bid);
-    else wgrad_reduce_body<64>(M.e[j], bid);
-}
-
-extern "C" int chap_wgrad_reduce_multi(const chap_wgrad_reduce_entry* E, int32_t n, void* stream) {
-    CHAP_CHECK_ARG(E && n > 0, "chap_wgrad_reduce_multi: bad argument");
-    CHAP_NOT_IN_GROUP("chap_wgrad_reduce_multi");
-    for (int i0 = 0; i0 < n; i0 += WG_MULTI) {
-        wgrad_reduce_multi_args M;
-        M.n = n - i0 < WG_MULTI ? n - i0 : WG_MULTI;
-        int blocks = 0;
-        for (int k = 0; k < M.n; ++k) {
-            const chap_wgrad_reduce_entry& e = E[i0 + k];
-            CHAP_CHECK_ARG(e.ws && e.dw && e.nsplit > 0 && e.nblocks > 0 && (e.e4 == 8 || e.e4 == 64), "chap_wgrad_reduce_multi: entry %d was not filled by chap_wgrad", i0 + k);
-            M.e[k] = wgrad_reduce_args{e.ws, e.ws_db, e.nsplit, e.taps, e.Ca, e.Cb, e.dw, (long)e.s_tap, (long)e.s_kc, (long)e.s_kn, e.kc_valid, e.kn_valid, e.db, e.nb_dw};
-            M.e4[k] = e.e4;
-            M.first[k] = blocks;
-            blocks += e.nblocks;
-        }
-        for (int k = M.n; k < WG_MULTI; ++k) { M.e[k] = M.e[0]; M.e4[k] = M.e4[0]; }
-        for (int k = M.n; k <= WG_MULTI; ++k) M.first[k] = blocks;
-        hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, M);
-        CHAP_LAUNCH_CHECK("chap_wgrad_reduce_multi");
-    }
-    return CHAP_OK;
-}
-
 extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->dw && p->ws && p->b.ptr && p->a[0].ptr, "chap_wgrad: null argument");
     wg_plan q;
@@ -177,11 +141,6 @@ extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     CHAP_CHECK_ARG(p->ID == (p->stride == 1 ? p->D : p->D * sd) && p->IH == p->H * p->stride && p->IW == p->W * p->stride,
                    "chap_wgrad: A dims (%d,%d,%d) do not match grid (%d,%d,%d) stride %d", p->ID, p->IH, p->IW, p->D, p->H, p->W, p->stride);
     if (p->dims == 3 && (p->a[0].keep || (p->na > 1 && p->a[1].keep))) { chap_set_error("chap_wgrad: element keep masks on the A operand are built for 2D only"); return CHAP_EUNSUPPORTED; }
-    if (p->bgrad.dy) {         // B computed on the fly (chap_bgrad_t)
-        CHAP_CHECK_ARG(p->bgrad.sums && p->bgrad.mean && p->bgrad.invstd && p->bgrad.gamma && p->bgrad.count > 0, "chap_wgrad: bgrad needs sums, mean, invstd, gamma, count");
-        CHAP_CHECK_ARG(p->bgrad.dy_ld % 8 == 0 && p->bgrad.dy_coff % 8 == 0 && p->bgrad.dy_ld >= p->bgrad.dy_coff + p->b.C, "chap_wgrad: bgrad.dy ld=%d coff=%d", p->bgrad.dy_ld, p->bgrad.dy_coff);
-        CHAP_CHECK_ARG(p->b.scale && p->b.C % 8 == 0, "chap_wgrad: bgrad needs b = the raw conv output with its forward BatchNorm affine");
-    }
     float* ws = (float*)p->ws;
     float* ws_db = p->db ? ws + (size_t)q.nsplit * (q.slab / sizeof(float)) : nullptr;
     hipStream_t s = (hipStream_t)stream;
@@ -195,13 +154,6 @@ extern "C" int chap_wgrad(const chap_wgrad_params* p, void* stream) {
     const int e4 = q.nsplit >= 64 ? 8 : 64;      // (8 elements per block / 128 slab groups for the 768-split layers measured 25 us against 7 us: too few loads in flight per thread)
     const int nb_db = p->db ? cdiv(q.Cb, 4 * e4) : 0;
     ra.nb_dw = cdiv(total, 4 * e4);
-    if (p->deferred) {         // the caller reduces the slabs of many layers at once (chap_wgrad_reduce_multi)
-        chap_wgrad_reduce_entry* d = p->deferred;
-        d->ws = ws; d->ws_db = ws_db; d->dw = p->dw; d->db = p->db; d->s_tap = p->s_tap; d->s_kc = p->s_kc; d->s_kn = p->s_kn;
-        d->nsplit = q.nsplit; d->taps = q.taps; d->Ca = q.Ca; d->Cb = q.Cb; d->kc_valid = kcv; d->kn_valid = knv;
-        d->nb_dw = ra.nb_dw; d->nblocks = ra.nb_dw + nb_db; d->e4 = e4;
-        return CHAP_OK;
-    }
     if (e4 == 8) return chap_launch<wgrad_reduce_args, wgrad_reduce_kernel<8>, 256>(dim3(ra.nb_dw + nb_db), dim3(256), 0, s, ra, "chap_wgrad(reduce)");
     return chap_launch<wgrad_reduce_args, wgrad_reduce_kernel<64>, 256>(dim3(ra.nb_dw + nb_db), dim3(256), 0, s, ra, "chap_wgrad(reduce)");
 }

@@ -11,7 +11,6 @@
 // (deterministic, no float atomics) and accumulates into the checkpoint-layout gradient.
 #pragma once
 #include "conv_kernel.h"
-#include "actbwd_math.h"
 
 constexpr int WG_BN = 32;                       // B channels per block (16 for layers with <= 16 output channels)
 constexpr int WG_BDUMMY = 8;                    // elements behind each B tile: store target of threads without a B unit
@@ -51,10 +50,7 @@ __device__ __forceinline__ s16x4 lds_tr16(const bf16_t* p) {
 // argument block of one launch (launch.h): base_z = the kernel's own grid.z (B-channel chunks); a grouped launch stacks groups along z
 struct wgrad_args { chap_wgrad_params P; float* ws; float* ws_db; int nsplit, Ca, Cb, base_z; };
 
-// GB ("lazy gradient", chap_bgrad_t): the B operand is computed while it is staged -- B = g = the BatchNorm / activation backward of the
-// incoming gradient dy and the raw conv output x (P.b), the apply phase of chap_act_bwd_* -- and the blocks of the first A-chunk store g
-// for the input-gradient convolution that follows.  Same arithmetic (actbwd_math.h), same bf16 rounding as the separate apply launch.
-template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int BN = WG_BN, int PD = 1, bool ZW = false, bool GB = false>
+template <typename T, int KS, int ST, bool D3, int KC, int MR, bool ADD2, int BN = WG_BN, int PD = 1, bool ZW = false>
 __device__ __forceinline__ void wgrad_kernel(const wgrad_args& A, int nb) {      // runs behind chap_grouped_z<.., 256, 1>
     const chap_wgrad_params& P = A.P;
     float* __restrict__ ws = A.ws;
@@ -141,11 +137,9 @@ __device__ __forceinline__ void wgrad_kernel(const wgrad_args& A, int nb) {     
     for (int j = 0; j < 8; ++j) dbsum[j] = 0.f;
     const bool want_db = ws_db != nullptr && chunk == 0;
 
-    struct pre_t { halo_regs<T, UNITS, ADD2, !D3> R; F braw[BUNITS]; F bdy[GB ? BUNITS : 1]; uint2 bkeep[BUNITS]; unsigned bok; int n; long gp0; };
+    struct pre_t { halo_regs<T, UNITS, ADD2, !D3> R; F braw[BUNITS]; uint2 bkeep[BUNITS]; unsigned bok; int n; };
     pre_t S[PD];                                                // register sets of the tiles in flight (compile-time indexed)
     f32x2 ba[4], bb2[4];                                        // scale/shift of this thread's 8 B channels
-    float gk0[GB ? 8 : 1], gcB[GB ? 8 : 1], gcC[GB ? 8 : 1], gsa[GB ? 8 : 1], gsb[GB ? 8 : 1];      // GB: BatchNorm-backward constants, forward scale / shift
-    const bool write_g = GB && P.bgrad.gout != nullptr && chunk == 0 && bchan_ok;
     const int cbB_safe = bchan_ok ? cbB : 0;
 
     // all loads unconditional (out-of-range units read the tile origin and are zeroed at commit): see halo_issue
@@ -157,7 +151,6 @@ __device__ __forceinline__ void wgrad_kernel(const wgrad_args& A, int nb) {     
         Q.n = n;
         halo_issue<T, KS, ST, D3, KC, MR, ADD2, UNITS, ZW>(R, U, s0, s1, P.ID, P.IH, P.IW, n, z0, y0, x0, chunk, lanesel);
         const long gp0 = (((long)n * P.D + z0) * P.H + y0) * P.W + x0;
-        Q.gp0 = gp0;
         const char* bb = (const char*)sb.ptr + (gp0 * sb.ld + sb.coff + cbB_safe) * (long)sizeof(T);
         const unsigned ldb = sb.ld * sizeof(T);
         unsigned r[BUNITS];
@@ -171,12 +164,6 @@ __device__ __forceinline__ void wgrad_kernel(const wgrad_args& A, int nb) {     
         }
 #pragma unroll
         for (int j = 0; j < BUNITS; ++j) braw[j] = frag<T>::load((const T*)(bb + __umul24(r[j], ldb)));
-        if constexpr (GB) {
-            const char* db_ = (const char*)P.bgrad.dy + (gp0 * P.bgrad.dy_ld + P.bgrad.dy_coff + cbB_safe) * (long)sizeof(T);
-            const unsigned ldd = P.bgrad.dy_ld * sizeof(T);
-#pragma unroll
-            for (int j = 0; j < BUNITS; ++j) Q.bdy[j] = frag<T>::load((const T*)(db_ + __umul24(r[j], ldd)));
-        }
         if (sb.has_keep) {
             const uint8_t* kb = sb.keep + gp0 * sb.C + cbB_safe;
 #pragma unroll
@@ -200,30 +187,6 @@ __device__ __forceinline__ void wgrad_kernel(const wgrad_args& A, int nb) {     
         for (int j = 0; j < BUNITS; ++j) {                      // threads without a unit stage zeros into the dummy slot
             T* dst = bt + b_lds[j];
             const bool ok = (bok >> j) & 1u;
-            if constexpr (GB) {
-                float xv[8], dyv[8], dz[8], gg[8];
-                frag<T>::unpack(braw[j], xv);
-                frag<T>::unpack(Q.bdy[j], dyv);
-                actbwd_deriv8(xv, dyv, gsa, gsb, P.b.act != 0, P.b.slope, dz);
-                if (sb.has_keep) actbwd_keep8(dz, bkeep[j], sb.keep_scale);
-                if (sb.has_cm) {
-                    float bcm[8];
-                    ld8(sb.chan_mul + (long)n * sb.C + cbB_safe, bcm);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) dz[k] *= bcm[k];
-                }
-                actbwd_apply8(dz, xv, gk0, gcB, gcC, gg);
-                const F gf = frag<T>::pack(gg);                  // the element type's rounding: what a stored g would hold
-                if (want_db) {
-                    float v[8];
-                    frag<T>::unpack(gf, v);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) dbsum[k] += ok ? v[k] : 0.f;
-                }
-                frag<T>::store(dst, frag<T>::select(ok, gf));
-                if (write_g && ok) frag<T>::store((T*)P.bgrad.gout + (Q.gp0 + b_rel[j]) * (long)Cb + cbB, gf);
-                continue;
-            }
             if (plainB) {
                 if (want_db) {
                     float v[8];
@@ -271,14 +234,6 @@ __device__ __forceinline__ void wgrad_kernel(const wgrad_args& A, int nb) {     
     for (int k = 0; k < 4; ++k) {
         ba[k] = *(const f32x2*)(aff + 2 * AFFC + cbB_safe + 2 * k);
         bb2[k] = *(const f32x2*)(aff + 2 * AFFC + AFFC / 2 + cbB_safe + 2 * k);
-    }
-    if constexpr (GB) {        // per-channel constants of this thread's 8 B channels (the prologue of chap_act_bwd_apply)
-        float a0[8], a1[8], gm[8], mean[8], istd[8];
-        ld8(P.bgrad.sums + cbB_safe, a0); ld8(P.bgrad.sums + Cb + cbB_safe, a1);
-        ld8(P.bgrad.gamma + cbB_safe, gm); ld8(P.bgrad.mean + cbB_safe, mean); ld8(P.bgrad.invstd + cbB_safe, istd);
-        actbwd_consts8(a0, a1, gm, mean, istd, P.bgrad.count, gk0, gcB, gcC);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { gsa[2 * k] = ba[k].x; gsa[2 * k + 1] = ba[k].y; gsb[2 * k] = bb2[k].x; gsb[2 * k + 1] = bb2[k].y; }
     }
     if (my_tiles > 0) commit(S[0], halo0, bt0);
     __syncthreads();

@@ -11,8 +11,6 @@ into the model's flat gradient buffer.
 
 Reference semantics followed: code/networks/unet.py:44-292, code/networks/vnet.py:8-238.
 """
-import contextlib
-
 import torch
 
 from . import _lib as L
@@ -88,22 +86,15 @@ def zip_branches(a_ops, b_ops):
     return out
 
 
-def drive(gens, stream):
-    """Run step generators (Executor.forward_steps / backward_steps) in lockstep: at every step the lanes of all generators are
-    enqueued inside ONE grouped launch region (their same-shaped kernels become one grid), a single lane directly.  All generators
-    must make the same number of steps (same program, same options).  Returns their return values."""
-    results, done = [None] * len(gens), 0
+def drive(gen, stream):
+    """Run a step generator (Executor.forward_steps / backward_steps): the lanes of a step -- the same-shaped ops of the two decoders --
+    are enqueued inside ONE grouped launch region (their kernels become one grid), a single lane directly.  Returns the generator's
+    return value."""
     while True:
-        lanes = []
-        for i, g in enumerate(gens):
-            try:
-                lanes += next(g)
-            except StopIteration as e:
-                results[i], done = e.value, done + 1
-        if done:
-            if done != len(gens) or lanes:
-                raise RuntimeError("chap_amd: passes driven in lockstep made different numbers of steps")
-            return results
+        try:
+            lanes = next(gen)
+        except StopIteration as e:
+            return e.value
         if not lanes:
             continue
         if len(lanes) == 1:
@@ -116,40 +107,12 @@ def drive(gens, stream):
                     f()
 
 
-def lazy_gradient_enabled():
-    """CHAP_LAZY_GRAD=1 (lab / A-B switch, default 0): fold the apply phase of the BatchNorm / activation backward into the weight
-    gradient wherever a layer has one incoming gradient (chap_bgrad_t).  Bit-identical to the separate launch
-    (tests/test_kernels_bwd_gpu.py::test_lazy_gradient_in_wgrad_equals_the_apply_launch) and SLOWER on the whole iteration (round 3, two
-    on-box A/B pairs: 2D 6.76-6.80 -> 6.81-6.85 ms, 3D 14.93 -> 15.29-15.37 ms): the weight gradient -- a per-tile round-trip chain --
-    stages a second tensor, does the backward math in its commit phase and writes g, which costs more than the apply launch it replaces."""
-    import os
-    return os.environ.get("CHAP_LAZY_GRAD", "0") == "1"
-
-
-def wgrad_defer_enabled():
-    """CHAP_WGRAD_DEFER=1 (lab / A-B switch, default 0): the slab reductions of a backward pass's weight gradients as ONE multi-layer launch at its
-    end (chap_wgrad_reduce_multi) instead of one launch per layer.  Bit-identical; whole iteration, two on-box A/B pairs: 2D 6.75-6.78 ->
-    6.73-6.75 ms (noise level), 3D 14.99-15.00 -> 15.12-15.16 ms (slower: the reductions no longer overlap the input-gradient convs that follow
-    them, they all sit at the end of the chain)."""
-    import os
-    return os.environ.get("CHAP_WGRAD_DEFER", "0") == "1"
-
-
 def grouping_mode():
-    """CHAP_GROUP (lab / A-B switch): 0 = never group (round 2: decoders back to back where a pass cannot fork), 1 = group the
-    two decoders' same-shaped layers in the passes that cannot fork a second stream, 2 = group in every pass (no second stream),
-    3 = in a captured pass that cannot fork a stream the two decoders are PARALLEL BRANCHES of the graph on the one stream
-    (chap_capture_mark / _goto / _join, _lib.branches); eager passes as in mode 1."""
+    """CHAP_GROUP (lab / A-B switch): 0 = never group (round 2: decoders back to back where a pass cannot fork a second stream), 1 (default) =
+    group the two decoders' same-shaped layers in the passes that cannot fork one.  (Round 3 also measured grouping in EVERY pass, the
+    decoders as parallel graph branches on one stream and the weight gradients as graph leaves: all slower, removed -- DESIGN.md section 5.)"""
     import os
     return int(os.environ.get("CHAP_GROUP", "1"))
-
-
-def wgrad_leaf_enabled():
-    """CHAP_WGRAD_LEAF=1: under a graph capture the weight-gradient launches of a backward pass (and their slab reductions) are
-    LEAVES of the graph (_lib.leaves): they depend on the chain up to their layer, the chain does not wait for them, and the pass
-    joins them at its end -- nobody needs dW before the optimizer step."""
-    import os
-    return int(os.environ.get("CHAP_WGRAD_LEAF", "0"))
 
 
 class Saved:
@@ -276,14 +239,12 @@ class Executor:
     def forward(self, x, **kw):
         """x: fp32 [N, in_chns, *spatial] contiguous. Returns (list of planar fp32 logits, Saved|None, extras):
         extras = the activated values named in `want`, materialised as planar fp32 [N, C, *spatial]."""
-        return drive([self.forward_steps(x, **kw)], torch.cuda.current_stream().cuda_stream)[0]
+        return drive(self.forward_steps(x, **kw), torch.cuda.current_stream().cuda_stream)
 
-    def forward_steps(self, x, *, train, dtype, save, update_stats=True, drop_masks=None, rng=None, want=(), perturb=None, lock=False):
+    def forward_steps(self, x, *, train, dtype, save, update_stats=True, drop_masks=None, rng=None, want=(), perturb=None):
         """The forward pass as a generator of STEPS: each `yield` hands the driver (engine.drive) the lanes of one step -- a list
-        of callables that enqueue the step's kernels, one per lane (one op; or the same-shaped ops of the two decoders) -- and the
-        generator's return value is forward()'s.  Several passes of one network driven together run in lockstep: the lanes of
-        their steps become ONE grouped launch region each (chap_hip.h, chap_group_*).  lock: this pass is one of several driven
-        together (or must not use a second stream): the decoders run in lockstep, never on a forked stream."""
+        of callables that enqueue the step's kernels, one per lane (one op; or the same-shaped ops of the two decoders, which the
+        driver issues as ONE grouped launch region: chap_hip.h, chap_group_*) -- and the generator's return value is forward()'s."""
         prog, sd, dims = self.prog, self._sd(), self.prog.dims
         dev = x.device
         N = x.shape[0]
@@ -324,12 +285,9 @@ class Executor:
         cur_stream = torch.cuda.current_stream()
         branches = sorted({op.branch for op in prog.ops})
         # two decoders: on a second stream where this pass may fork one (eager; under capture only from the capture's origin
-        # stream), otherwise in lockstep with grouped launches.  CHAP_GROUP=2 (lab): lockstep everywhere.
-        side = self._side_stream(cur_stream) if (len(branches) > 2 and grouping_mode() != 2) else None
-        if lock:
-            side = None
-        branching = (side is None and not lock and len(branches) == 3 and grouping_mode() == 3 and torch.cuda.is_current_stream_capturing())
-        zipped = self._zipped() if (side is None and not branching and len(branches) == 3 and (lock or grouping_mode() != 0)) else None
+        # stream), otherwise in lockstep with grouped launches
+        side = self._side_stream(cur_stream) if len(branches) > 2 else None
+        zipped = self._zipped() if (side is None and len(branches) == 3 and grouping_mode() != 0) else None
 
         # Dropout seeds are drawn HERE, in program order: the order in which the ops are ISSUED depends on whether this pass
         # may fork its second decoder (eager / captured, which stream), and a seed must not (round 2: the early VAT pass drew
@@ -490,16 +448,6 @@ class Executor:
             # and no second stream (which a captured pass on a forked stream could not have, see _side_stream)
             for pair in zipped:
                 yield [lambda op=op: run_dec(op) for op in pair]
-        elif branching:
-            # a captured pass on a stream that cannot fork another one: the decoders as two parallel branches of the graph on THIS stream
-            with L.branches(cur_stream.cuda_stream) as br:
-                for op in prog.ops:
-                    if op.branch == 1:
-                        run_dec(op)
-                br.next()
-                for op in prog.ops:
-                    if op.branch >= 2:
-                        run_dec(op)
         elif side is not None:
             side.wait_stream(cur_stream)
             with torch.cuda.stream(side):
@@ -527,9 +475,9 @@ class Executor:
     def backward(self, S, dlogits, **kw):
         """dlogits: list (per head) of planar fp32 gradients or None. Accumulates parameter gradients
         into the module's flat grad views; returns dx (fp32, shape of x) or None."""
-        return drive([self.backward_steps(S, dlogits, **kw)], torch.cuda.current_stream().cuda_stream)[0]
+        return drive(self.backward_steps(S, dlogits, **kw), torch.cuda.current_stream().cuda_stream)
 
-    def backward_steps(self, S, dlogits, *, dtype, need_wgrad, need_dx, grad_buffer=None, lock=False):
+    def backward_steps(self, S, dlogits, *, dtype, need_wgrad, need_dx, grad_buffer=None):
         """The backward pass as a generator of steps (see forward_steps); returns dx."""
         prog, sd, dims = self.prog, self._sd(), self.prog.dims
         gr = None
@@ -537,9 +485,6 @@ class Executor:
             gr = self.m.grad_views_of(grad_buffer) if grad_buffer is not None else self.m._grad_views()
         dev = S.x.device
         N = S.x.shape[0]
-        # the slab reductions of the weight gradients are not needed before the optimizer: ONE multi-layer launch at the end of the pass instead
-        # of one launch per layer on its chain (CHAP_WGRAD_DEFER=0: the immediate reduction of rounds 1-2)
-        deferred = [] if (need_wgrad and wgrad_defer_enabled()) else None
         contrib = {}        # value name -> list of (tensor, coff, index of the op whose backward produced it)
         okey = {id(op): i for i, op in enumerate(prog.ops)}
 
@@ -549,12 +494,6 @@ class Executor:
             and eager, captured and data-parallel runs must agree bit for bit."""
             c = contrib.get(name)
             return None if not c else [(t, o) for t, o, _ in sorted(c, key=lambda e: e[2])]
-
-        lv = [None]         # the open _lib.leaves region of the stream the ops are being issued on (CHAP_WGRAD_LEAF)
-
-        def leaf(bgrad=None):
-            # (with the lazy gradient the weight gradient WRITES g for the input-gradient conv: on the chain)
-            return lv[0].leaf() if (lv[0] is not None and bgrad is None) else contextlib.nullcontext()
 
         pooled = {}         # value name -> (grad tensor, idx)
         head_g = dict(zip(prog.heads, dlogits))
@@ -606,7 +545,7 @@ class Executor:
                     contrib.setdefault(op.srcs[0], []).append((o, 0, okey[id(op)]))
                 return
             # ---- gradient w.r.t. the raw output of this conv
-            bgrad, v = None, None
+            v = None
             if op.head:
                 dl = head_g.get(op.out)
                 if dl is None:
@@ -624,7 +563,6 @@ class Executor:
                 v = V[op.out]
                 gd = S.dims[op.out]
                 kn_valid = 0
-                bgrad = None
                 plain = (v.scale is None and not v.act and v.keep is None and v.chan_mul is None)
                 if plain and pl is None and len(c) == 1:
                     g = Lazy(c[0][0], C=v.C, coff=c[0][1])
@@ -646,30 +584,22 @@ class Executor:
                             kw.update(dgamma=gr[op.bn + ".weight"], dbeta=gr[op.bn + ".bias"])
                     if op.bn:
                         kw["sums"] = take_sums(v.C)
-                    # "lazy gradient" (round 3): with ONE incoming gradient under a training-mode BatchNorm the apply phase runs inside the
-                    # weight gradient's B staging (chap_bgrad_t) -- one launch and one pass over dy and x less; the weight gradient stores g
-                    # for the input-gradient conv below.  Not for the transposed conv (there g is the A operand) or the fp32 first layer.
-                    fuse = bool(lazy_gradient_enabled() and need_wgrad and op.bn and S.train and c and len(c) == 1 and pl is None and
-                                (k in ("conv", "down") or (k == "c1" and S.xpad is not None)))
-                    ops.act_bwd(v, c or [], gout, g_pool=pl[0] if pl else None, pool_idx=pl[1] if pl else None, apply=not fuse, **kw)
+                    ops.act_bwd(v, c or [], gout, g_pool=pl[0] if pl else None, pool_idx=pl[1] if pl else None, **kw)
                     g = Lazy(gout)
-                    if fuse:
-                        bgrad = dict(dy=c[0], sums=kw["sums"], mean=kw["mean"], invstd=kw["invstd"], gamma=kw["gamma"], count=kw["count"], gout=gout)
             # ---- this conv's own backward
             if k == "c1":
                 D, H, W = S.dims[op.out]
                 gt = g.raw if (g.coff == 0 and g.C == g.ld) else None
                 assert gt is not None
-                if need_wgrad:      # (first: with the lazy gradient it is the weight gradient that writes g)
-                    with leaf(bgrad):
-                        if S.xpad is not None:
-                            taps = 3 ** dims
-                            cin = S.x.shape[1]
-                            ops.wgrad([Lazy(S.xpad)], v if bgrad else g, gr[op.w], (1, taps, cin * taps), grid=(n, D, H, W), in_dims=(D, H, W),
-                                      ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=cin, bgrad=bgrad, defer=deferred)
-                        else:
-                            ops.conv_c1_bwd(gt, sd[op.w], S.x.view(n, D, H, W), dims=dims, dx=None,
-                                            dw=gr[op.w], db=gr[op.b] if op.b else None)
+                if need_wgrad:
+                    if S.xpad is not None:
+                        taps = 3 ** dims
+                        cin = S.x.shape[1]
+                        ops.wgrad([Lazy(S.xpad)], g, gr[op.w], (1, taps, cin * taps), grid=(n, D, H, W), in_dims=(D, H, W),
+                                  ksize=3, stride=1, dims=dims, db=gr[op.b] if op.b else None, kc_valid=cin)
+                    else:
+                        ops.conv_c1_bwd(gt, sd[op.w], S.x.view(n, D, H, W), dims=dims, dx=None,
+                                        dw=gr[op.w], db=gr[op.b] if op.b else None)
                 if need_dx:
                     dx = L.hold_empty_like(S.x)      # [n, in_chns, *spatial] fp32 == planar output
                     wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
@@ -682,9 +612,8 @@ class Executor:
             if k == "conv":
                 taps = op.ksize ** dims
                 if need_wgrad:
-                    with leaf(bgrad):
-                        ops.wgrad(srcs, v if bgrad else g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
-                                  ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid, bgrad=bgrad, defer=deferred)
+                    ops.wgrad(srcs, g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
+                              ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid)
                 wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
@@ -692,9 +621,8 @@ class Executor:
             elif k == "down":
                 gdd = S.dims[op.out]
                 if need_wgrad:
-                    with leaf(bgrad):
-                        ops.wgrad(srcs, v if bgrad else g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
-                                  ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, bgrad=bgrad, defer=deferred)
+                    ops.wgrad(srcs, g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
+                              ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None)
                 wp = self._pack(op, L.PACK_DOWN_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, nsub * ctot, dsrc, grid=(n,) + gdd, in_dims=gdd, ksize=1, stride=1, dims=dims,
@@ -704,11 +632,10 @@ class Executor:
                 fine = S.dims[op.out]
                 if need_wgrad:
                     assert len(srcs) == 1
-                    with leaf():
-                        ops.wgrad([g], srcs[0], gr[op.w], (1, nsub, op.cout * nsub), grid=(n, sd_, sh_, sw_), in_dims=fine,
-                                  ksize=2, stride=2, dims=dims, defer=deferred)
-                        if op.b:
-                            ops.channel_sum(g, gr[op.b])
+                    ops.wgrad([g], srcs[0], gr[op.w], (1, nsub, op.cout * nsub), grid=(n, sd_, sh_, sw_), in_dims=fine,
+                              ksize=2, stride=2, dims=dims)
+                    if op.b:
+                        ops.channel_sum(g, gr[op.b])
                 wp = self._pack(op, L.PACK_DECONV_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=fine, ksize=2, stride=2, dims=dims)
@@ -717,58 +644,30 @@ class Executor:
         cur_stream = torch.cuda.current_stream()
         rev = list(reversed(prog.ops))
         nbr = len({op.branch for op in prog.ops})
-        side = self._side_stream(cur_stream) if (nbr > 2 and grouping_mode() != 2) else None
-        if lock:
-            side = None
-        capturing = torch.cuda.is_current_stream_capturing()
-        branching = side is None and not lock and nbr == 3 and grouping_mode() == 3 and capturing
-        zipped = self._zipped() if (side is None and not branching and nbr == 3 and (lock or grouping_mode() != 0)) else None
-        # weight gradients as leaves of the captured graph (never inside a grouped launch region: lanes are issued at the region's end)
-        wl = wgrad_leaf_enabled()        # 1: every captured pass, 2: only the passes on the capture's origin stream (the iteration's long chain)
-        leafing = bool(need_wgrad and capturing and zipped is None and not lock and (wl == 1 or (wl == 2 and side is not None)))
-        with L.leaves(cur_stream.cuda_stream, enabled=leafing) as lv_main:
-            lv[0] = lv_main if lv_main.active else None
-            if zipped is not None:
-                for pair in reversed(zipped):
-                    yield [lambda op=op: bwd_op(op) for op in pair]
-                for op in rev:
-                    if op.branch == 0:
-                        yield [lambda op=op: bwd_op(op)]
-            elif branching:
-                with L.branches(cur_stream.cuda_stream) as br:
-                    for op in rev:
-                        if op.branch == 1:
-                            bwd_op(op)
-                    br.next()
-                    for op in rev:
-                        if op.branch >= 2:
-                            bwd_op(op)
-                for op in rev:
-                    if op.branch == 0:
-                        bwd_op(op)
-            elif side is not None:
-                side.wait_stream(cur_stream)
-                with torch.cuda.stream(side):
-                    # (the side stream's leaves are its own: joined before the main stream waits for it)
-                    with L.leaves(side.cuda_stream, at=L.SLOT_LEAF_AT + 2, acc=L.SLOT_LEAVES + 2, enabled=leafing) as lv_side:
-                        lv[0] = lv_side if lv_side.active else None
-                        for op in rev:
-                            if op.branch >= 2:
-                                bwd_op(op)
-                lv[0] = lv_main if lv_main.active else None
-                for op in rev:
-                    if op.branch == 1:
-                        bwd_op(op)
-                cur_stream.wait_stream(side)
-                for op in rev:
-                    if op.branch == 0:
-                        bwd_op(op)
-            else:
-                for op in rev:
+        side = self._side_stream(cur_stream) if nbr > 2 else None
+        zipped = self._zipped() if (side is None and nbr == 3 and grouping_mode() != 0) else None
+        if zipped is not None:
+            for pair in reversed(zipped):
+                yield [lambda op=op: bwd_op(op) for op in pair]
+            for op in rev:
+                if op.branch == 0:
                     yield [lambda op=op: bwd_op(op)]
-        lv[0] = None
-        if deferred:            # (runs when the driver asks for the next step, outside any launch region)
-            ops.wgrad_reduce_multi(deferred)
+        elif side is not None:
+            side.wait_stream(cur_stream)
+            with torch.cuda.stream(side):
+                for op in rev:
+                    if op.branch >= 2:
+                        bwd_op(op)
+            for op in rev:
+                if op.branch == 1:
+                    bwd_op(op)
+            cur_stream.wait_stream(side)
+            for op in rev:
+                if op.branch == 0:
+                    bwd_op(op)
+        else:
+            for op in rev:
+                yield [lambda op=op: bwd_op(op)]
         return dx
 
     @staticmethod

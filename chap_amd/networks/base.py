@@ -218,39 +218,6 @@ class ChapNet(nn.Module):
         dl = [None if g is None else g.contiguous() for g in dlogits]
         return self._exec.backward(ctx.S, dl, dtype=self.compute_dtype, need_wgrad=need_wgrad, need_dx=need_dx, grad_buffer=grad_buffer)
 
-    # ------------------------------------------------------------------ several passes in lockstep (grouped launches)
-    def forward_lockstep(self, passes):
-        """Run several forward passes of this network TOGETHER, op by op: the same layer of every pass (and of both decoders) is
-        one grouped launch (chap_hip.h, chap_group_*) -- e.g. pass A on the unlabeled half and the first VAT forward
-        (train_ours_2D.py:314,372), or pass B and the final VAT pass (:339,372).  The passes must be independent of each other.
-        passes: dicts with x [N, 1, *spatial] and optionally save (keep the state for backward_lockstep), update_stats,
-        drop_masks.  Not an autograd node: returns [(logits list, saved state or None)], backward = backward_lockstep."""
-        from ..engine import drive
-        self._ensure_flat()
-        gens = []
-        for ps in passes:
-            x = ps["x"]
-            if x.dim() != self.dims + 2 or x.shape[1] != self.in_chns:
-                raise ValueError("chap_amd: expected input [N, %d, %s], got %s" % (self.in_chns, ", ".join("*" * self.dims), tuple(x.shape)))
-            if x.dtype != torch.float32 or not x.is_contiguous():
-                x = x.float().contiguous()
-            gens.append(self._exec.forward_steps(x.detach(), train=self.training, dtype=self.compute_dtype, save=bool(ps.get("save", False)),
-                                                 update_stats=ps.get("update_stats", True), drop_masks=ps.get("drop_masks"), rng=self._rng, lock=True))
-        return [(lg, S) for lg, S, _ in drive(gens, torch.cuda.current_stream().cuda_stream)]
-
-    def backward_lockstep(self, items):
-        """Backward passes of forward_lockstep passes, together.  items: dicts with S (the saved state), dlogits (per head),
-        and optionally need_wgrad (default True), need_dx, grad_buffer (flat buffer the parameter gradients are accumulated into;
-        the passes of one call must use DIFFERENT buffers: their lanes run concurrently).  Returns the input gradients (or None)."""
-        from ..engine import drive
-        bufs = [id(it.get("grad_buffer")) for it in items if it.get("need_wgrad", True)]
-        if len(set(bufs)) != len(bufs):
-            raise ValueError("chap_amd: passes driven in lockstep must accumulate their parameter gradients into different buffers")
-        gens = [self._exec.backward_steps(it["S"], [None if g is None else g.contiguous() for g in it["dlogits"]], dtype=self.compute_dtype,
-                                          need_wgrad=it.get("need_wgrad", True), need_dx=it.get("need_dx", False), grad_buffer=it.get("grad_buffer"), lock=True)
-                for it in items]
-        return drive(gens, torch.cuda.current_stream().cuda_stream)
-
     def release_saved(self, out):
         ctx = out.grad_fn
         if ctx is not None:

@@ -139,16 +139,8 @@ def conv_c1_bwd(g, w, x, *, dims, dx=None, dw=None, db=None):
     L.call("chap_conv_c1_bwd", p, _stream())
 
 
-def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine=0, db=None, kc_valid=0, kn_valid=0, bgrad=None, defer=None):
-    """bgrad (chap_bgrad_t, "lazy gradient"): dict(dy=(tensor, coff), sums=, mean=, invstd=, gamma=, count=, gout=) -- `b` is then the RAW conv
-    output with its forward transform and the B operand g = BatchNorm / activation backward of dy is computed while it is staged (and stored
-    to gout for the input-gradient conv): chap_act_bwd_apply folded into this launch."""
+def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine=0, db=None, kc_valid=0, kn_valid=0):
     p = L.WgradParams()
-    if bgrad is not None:
-        dy, coff = bgrad["dy"]
-        p.bgrad.dy, p.bgrad.dy_ld, p.bgrad.dy_coff = dy.data_ptr(), dy.shape[-1], coff
-        p.bgrad.sums, p.bgrad.mean, p.bgrad.invstd, p.bgrad.gamma = bgrad["sums"].data_ptr(), bgrad["mean"].data_ptr(), bgrad["invstd"].data_ptr(), bgrad["gamma"].data_ptr()
-        p.bgrad.count, p.bgrad.gout = float(bgrad["count"]), _p(bgrad.get("gout"))
     for i, s in enumerate(a_srcs):
         s.fill(p.a[i])
     p.na, p.combine = len(a_srcs), combine
@@ -164,19 +156,7 @@ def wgrad(a_srcs, b, dw, strides, *, grid, in_dims, ksize, stride, dims, combine
     nbytes = L.size_of("chap_wgrad_ws", p)
     ws = L.hold_empty(max(nbytes, 16), dtype=torch.uint8, device=dw.device)
     p.ws, p.ws_bytes = ws.data_ptr(), nbytes
-    if defer is not None:        # `defer`: a list; the slab reduction is left to wgrad_reduce_multi(defer) (one launch for many layers)
-        import ctypes as C
-        entry = L.WgradReduceEntry()
-        p.deferred = C.pointer(entry)
-        defer.append((entry, ws))               # the workspace lives until the reduction has been enqueued
     L.call("chap_wgrad", p, _stream())
-
-
-def wgrad_reduce_multi(defer):
-    """Reduce the slabs of every weight gradient recorded in `defer` (see wgrad) and empty the list."""
-    if defer:
-        L.wgrad_reduce_multi([e for e, _ in defer], _stream())
-        del defer[:]
 
 
 def bn_finalize(stats, gamma, beta, running_mean, running_var, nbt, count, eps, momentum,
@@ -242,7 +222,7 @@ def _act_bwd_params(lazy, grads, g_pool, pool_idx, mean, invstd, gamma, sums, go
 
 
 def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=None, gamma=None,
-            dgamma=None, dbeta=None, count=1.0, bn_mode=None, sums=None, apply=True):
+            dgamma=None, dbeta=None, count=1.0, bn_mode=None, sums=None):
     """grads: list of (tensor, channel offset).
     bn_mode 1 (default when mean is given): training-mode BN backward fused in;
     bn_mode 2: fixed affine (eval-mode BN), dgamma/dbeta from the same reduction when requested."""
@@ -255,8 +235,7 @@ def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=
     p.bn = bn_mode
     if need_reduce:
         L.call("chap_act_bwd_reduce", p, _stream())
-    if apply:               # apply=False: the caller folds the apply phase into the weight gradient (wgrad(bgrad=...)); `sums` row 0 holds the totals
-        L.call("chap_act_bwd_apply", p, _stream())
+    L.call("chap_act_bwd_apply", p, _stream())
     return sums
 
 

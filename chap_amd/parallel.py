@@ -23,14 +23,30 @@ the eager collectives behind graph B / graph V, then [optimizer graph] (chap_amd
 import torch
 
 
+BUCKET_BYTES = 16 << 20     # the 3D gradient buffer (49.4 MB) goes out in pieces of <= 16 MB; the 2D one (10.3 MB) is one piece
+
+
 class DataParallelSync:
-    def __init__(self, both_buckets, dist, group=None, overlap=False):
+    """bucket_bytes: a gradient half is all-reduced in contiguous pieces of at most this many bytes, issued back to back on the collective's
+    stream (a ring over xGMI is per-link bound: pieces of a few MB keep every link busy while the next piece is being set up, and a later
+    schedule can start the first pieces before the last gradients are final).  The element-wise sum does not depend on the partition: any
+    bucket size gives the same bits (tests/test_parallel_cpu.py, tests/test_parallel_gpu.py: 1-rank RCCL group == the plain step)."""
+
+    def __init__(self, both_buckets, dist, group=None, overlap=False, bucket_bytes=BUCKET_BYTES):
         self.buf, self.dist, self.group, self.overlap = both_buckets, dist, group, overlap
-        self.work, self.work0 = None, None
+        self.bucket_elems = max(1, int(bucket_bytes) // both_buckets.element_size())
+        self.work, self.work0 = [], []
 
     def _halves(self):
         n = self.buf.numel() // 2
         return self.buf[:n], self.buf[n:]
+
+    def pieces(self, t):
+        """The contiguous <= bucket_bytes pieces of a flat gradient half, in order."""
+        return [t[i:i + self.bucket_elems] for i in range(0, t.numel(), self.bucket_elems)]
+
+    def _all_reduce(self, t):
+        return [self.dist.all_reduce(p, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True) for p in self.pieces(t)]
 
     def start_first(self):
         """Bucket 0 is final on the CURRENT stream (phase B's): start its all-reduce now; it runs beside whatever the
@@ -38,14 +54,14 @@ class DataParallelSync:
         if not self.overlap:
             return
         b0, _ = self._halves()
-        self.work0 = self.dist.all_reduce(b0, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.work0 = self._all_reduce(b0)
 
     def start(self):
         """All gradients have been enqueued on the current stream: all-reduce what is still outstanding (bucket 1 when
         bucket 0 went ahead with start_first; otherwise fold bucket 1 into bucket 0 and all-reduce that half)."""
         b0, b1 = self._halves()
-        if self.work0 is not None:
-            self.work = self.dist.all_reduce(b1, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if self.work0:
+            self.work = self._all_reduce(b1)
             return
         if b0.is_cuda:
             from . import ops
@@ -53,14 +69,13 @@ class DataParallelSync:
         else:
             b0.add_(b1)                             # gloo rehearsal on CPU tensors (tests/test_parallel_cpu.py)
         b1.zero_()
-        self.work = self.dist.all_reduce(b0, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.work = self._all_reduce(b0)
 
     def wait(self):
         """The current stream (the optimizer's) waits for the collectives."""
-        for w in (self.work0, self.work):
-            if w is not None:
-                w.wait()
-        self.work0 = self.work = None
+        for w in self.work0 + self.work:
+            w.wait()
+        self.work0, self.work = [], []
 
 
 class HostStagedDist:

@@ -72,6 +72,25 @@ def _distinct_streams(dev, n):
     raise RuntimeError("chap_amd: could not get %d distinct streams from the pool" % n)
 
 
+def check_graph_environment(concurrent=True, environ=None):
+    """Refuse a graph capture the runtime is known to die in.  The captured iteration forks four streams (capture origin, pass B, second decoder,
+    early VAT pass); with GPU_MAX_HW_QUEUES below 3 the FIRST REPLAY of any such graph aborts inside the ROCm 7.2 runtime with no HIP error
+    (profiles/r03_runtime_aborts.log: 2D and 3D, default schedule) -- a user-reachable environment, so capture() raises here instead.  A
+    single-stream iteration (ChapStep(args={'concurrent': False})) captures as one chain and is not affected."""
+    from ._lib import ChapError
+    env = os.environ if environ is None else environ
+    v = env.get("GPU_MAX_HW_QUEUES")
+    if v is None or not concurrent:
+        return
+    try:
+        n = int(v)
+    except ValueError:
+        return
+    if n < 3:
+        raise ChapError("chap_amd: GPU_MAX_HW_QUEUES=%d: the multi-stream HIP graph of the iteration needs at least 3 hardware queues (its first replay "
+                        "aborts in the runtime below that).  Unset GPU_MAX_HW_QUEUES (default 4) or build the step with args={'concurrent': False}." % n)
+
+
 class VAT2d:
     """adv_loss = VAT2d(xi, epi, num_classes); adv_loss(model, x, soft1, soft2, mask, losstype)
     (call sites train_ours_2D.py:290,372); losstype 'kl' or 'dice' (--adv_losstype, :515), `sign=True` = the FGSM-style
@@ -330,110 +349,7 @@ class ChapStep:
         with self.model.hold_stat_shift():          # one snapshot of the running means for all passes of the iteration (determinism)
             return self._iteration(volume_batch, label_batch, inject, update)
 
-    def _lockstep_ok(self):
-        """The lockstep schedule (args['lockstep'] = True or CHAP_LOCKSTEP=1; NOT the default: measured slower, see _iteration_lockstep)
-        covers the plain iteration; the channel-dropout branch (GradSim splits pass B's backward), a run without VAT power iterations
-        and the overlapped data-parallel schedule (bucket 0 all-reduced beside the VAT chain) always take the stream-parallel one."""
-        a = self.args
-        on = a.get("lockstep", os.environ.get("CHAP_LOCKSTEP", "0") != "0")
-        return bool(on) and self.concurrent and a["adv_noise"] and a["vat_iters"] >= 1 and not a["dropout"] and \
-            not (self.grad_sync is not None and getattr(self.grad_sync, "overlap", False))
-
-    def _iteration_lockstep(self, volume_batch, label_batch, inject=None, update=True):
-        """The iteration as THREE lockstep phases on one stream (round 3).  The four network passes of an iteration come in two
-        pairs that run the same layers on independent data: pass A (:314) with the first VAT forward on x + xi d (:372), and pass B
-        (:339, forward + backward) with the final VAT pass on x + r_adv (forward + backward).  Each pair is driven op by op
-        (ChapNet.forward_lockstep / backward_lockstep): the same layer of both passes -- and of both decoders -- is ONE grouped
-        launch (chap_hip.h, chap_group_*), bit-identical to separate launches (tests/test_train_step_gpu.py::
-        test_lockstep_schedule_equals_the_stream_parallel_schedule).  Between the pairs: pseudo labels, perturbation mask, the power
-        iteration's backward (one pass), and -- on a side stream, beside it -- the largest-CC filter and the BCP mixing that feed
-        pass B.  MEASURED (round 3, one MI355X, bf16, graph replay): ~45 % of the launches of the stream-parallel schedule, and SLOWER
-        -- 2D 7.94 vs 6.95 ms, 3D 18.0 vs 15.0 ms per step: a grid of 2-4 lanes takes as long as its lanes one after the other (the
-        layers already fill the CUs' block slots), while passes on separate streams overlap DIFFERENT kernels (a latency-bound deep
-        layer beside an HBM-bound full-resolution one).  Kept as an option and as the end-to-end test of grouped launches; the
-        default schedule stays stream-parallel, with grouped decoders only in the passes that cannot fork a stream (engine.py)."""
-        a, model = self.args, self.model
-        inject = inject or {}
-        nc, lbs = a["num_classes"], a["labeled_bs"]
-        B = volume_batch.shape[0]
-        lsub, usub, U = lbs // 2, (B - lbs) // 2, B - lbs
-        img_a, img_b = volume_batch[:lsub], volume_batch[lsub:lbs]
-        uimg_a, uimg_b, uimg_ab = volume_batch[lbs:lbs + usub], volume_batch[lbs + usub:], volume_batch[lbs:]
-        lab_a, lab_b = label_batch[:lsub], label_batch[lsub:lbs]
-        adv, mode = self.adv_loss, a["adv_losstype"]
-        if mode not in ops.DIST_MODES:
-            raise ValueError("chap_amd VAT2d: adv_losstype=%r (--adv_losstype {kl,dice}, train_ours_2D.py:515)" % (mode,))
-        main = torch.cuda.current_stream()
-        model.prepare_weights()
-        # ---- phase 1: the VAT start direction, then [first VAT forward | pass A] in lockstep (:314-325, :372)
-        x = volume_batch[-U:].contiguous()
-        d = torch.empty_like(x)
-        if inject.get("d0") is not None:
-            ops.l2_normalize(inject["d0"], d)
-        else:
-            ops.rand_uniform(d, model._rng.next_seed(), -0.5, 0.5, seed_dev=model._rng.seed_dev)
-            ops.l2_normalize(d, d)
-        xh = torch.empty_like(x)
-        ops.perturb(x, d, xh, adv.xi)
-        (first, S_v0), ((pre_ab1, pre_ab2), _) = model.forward_lockstep([
-            dict(x=xh, save=True, update_stats=False, drop_masks=inject.get("drop_V0")),          # listed first: it draws its dropout seeds first, as in the stream-parallel schedule
-            dict(x=uimg_ab, save=False, update_stats=True, drop_masks=inject.get("drop_A"))])
-        soft1, soft2, pseudo1, pseudo2, knowledge = ops.pseudo_block(pre_ab1, pre_ab2)
-        diff_mask = ops.diff_mask(pseudo1, pseudo2, knowledge, 4, a["topk1"])
-        # ---- beside phase 2, on the side stream: what pass B needs (:326-338)
-        loss_mask = torch.empty(lsub, *volume_batch.shape[2:], dtype=torch.int64, device=volume_batch.device)      # (allocated on the stream that uses them later)
-        net_input_mix = torch.empty((lsub + usub,) + tuple(volume_batch.shape[1:]), dtype=torch.float32, device=volume_batch.device)
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
-            if a["nms"]:
-                plab1, plab2 = ops.largest_cc(pseudo1, nc), ops.largest_cc(pseudo2, nc)
-                plab1.record_stream(main)
-                plab2.record_stream(main)
-            else:
-                plab1, plab2 = pseudo1, pseudo2
-            ops.box_mask(loss_mask, self.box)
-            ops.box_mix(img_b, uimg_b, net_input_mix[:lsub], self.box)
-            ops.box_mix(uimg_a, img_a, net_input_mix[lsub:], self.box)
-        # ---- phase 2: the power iteration(s): distance gradient, backward to the input only, normalise (DESIGN.md P1)
-        for it in range(adv.ip):
-            if it == 0:
-                (l1, l2), S = first, S_v0
-            else:
-                ops.perturb(x, d, xh, adv.xi)
-                ((l1, l2), S), = model.forward_lockstep([dict(x=xh, save=True, update_stats=False, drop_masks=inject.get("drop_V%d" % it))])
-            g1, g2 = torch.empty_like(l1), torch.empty_like(l2)
-            ops.kl_fwd_bwd((l1, l2), (soft1, soft2), None, (g1, g2), mode=mode)
-            dx, = model.backward_lockstep([dict(S=S, dlogits=[g1, g2], need_wgrad=False, need_dx=True)])
-            ops.l2_normalize(dx, d)
-        xa = torch.empty_like(x)
-        alpha = adv.epi / math.sqrt(x[0].numel()) if adv.sign else adv.epi
-        ops.perturb(x, d, xa, alpha, mask=diff_mask.reshape(x.shape), sign=adv.sign)
-        main.wait_stream(self._side)
-        # ---- phase 3: [pass B | final VAT pass] forward, the losses, backward -- in lockstep (:339-351, :372-378)
-        ((out_mix1, out_mix2), S_b), ((v1, v2), S_v) = model.forward_lockstep([
-            dict(x=net_input_mix, save=True, update_stats=True, drop_masks=inject.get("drop_B")),
-            dict(x=xa, save=True, update_stats=False, drop_masks=inject.get("drop_VF"))])
-        d1, d2 = torch.empty_like(out_mix1), torch.empty_like(out_mix2)
-        plab_a1, plab_b1, plab_a2, plab_b2 = plab1[:usub], plab1[usub:], plab2[:usub], plab2[usub:]
-        terms = ((out_mix1[lsub:], d1[lsub:], plab_a2, lab_a, True), (out_mix2[lsub:], d2[lsub:], plab_a1, lab_a, True),
-                 (out_mix1[:lsub], d1[:lsub], lab_b, plab_b2, False), (out_mix2[:lsub], d2[:lsub], lab_b, plab_b1, False))
-        losses = []
-        for lg, dl, img_l, patch_l, unlab in terms:
-            iw, pw = (0.5, 1.0) if unlab else (1.0, 0.5)            # l_weight=1.0, u_weight=0.5 (:198-203)
-            loss3, acc = ops.mix_loss_fwd(lg, img_l, patch_l, loss_mask, iw, pw)
-            ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, iw, pw, acc, dl)
-            losses.append(loss3)
-        vat_loss = torch.zeros(1, dtype=torch.float32, device=x.device)
-        g1, g2 = torch.empty_like(v1), torch.empty_like(v2)
-        ops.kl_fwd_bwd((v1, v2), (soft1, soft2), vat_loss, (g1, g2), gscale=1.0, gscale_dev=self.cw_dev, mode=mode)
-        model.backward_lockstep([dict(S=S_b, dlogits=[d1, d2]), dict(S=S_v, dlogits=[g1, g2], grad_buffer=self.grad2)])
-        if update:
-            self.exchange_and_update()
-        return {"mix_losses": losses, "vat_loss": vat_loss}
-
     def _iteration(self, volume_batch, label_batch, inject=None, update=True):
-        if type(self)._iteration is ChapStep._iteration and self._lockstep_ok():
-            return self._iteration_lockstep(volume_batch, label_batch, inject, update)
         main = torch.cuda.current_stream()
         with self._decoder_fork(main):
             ctx = self._phase_a(volume_batch, label_batch, inject)
@@ -624,6 +540,7 @@ class ChapStep:
         afterwards, so capture() does not train -- without it they count as `warmup` real iterations.  The captured pass
         itself is not executed: iter_num == number of applied updates at all times.  `inject` (tests): static tensors
         (dropout masks, VAT noise) the captured iteration reads instead of drawing its own."""
+        check_graph_environment(self.concurrent)
         self._hw = tuple(volume_batch.shape[2:])
         self._static_v = volume_batch.clone()
         self._static_l = label_batch.clone()

@@ -35,9 +35,13 @@
  *      sums, the loss accumulators (chap_mix_loss_*: acc is a workspace of partial rows), chap_kl_fwd_bwd (ws),
  *      chap_channel_sum (ws), chap_l2_normalize (ws = N * CHAP_L2NORM_SLOTS floats) likewise.  chap_kl_fwd_bwd: `mode`
  *      (KL or Dice distance).  chap_grad_sim.
- *   6  chap_capture_mark / chap_capture_goto / chap_capture_join: parallel branches of a captured graph on one stream
  *   5  chap_group_begin / chap_group_next_lane / chap_group_end: grouped launches of same-shaped layers (the two decoders of a
  *      DualDecoder, two passes of one network) -- one grid instead of 2-4, bit-identical results.
+ *   6  (round 3, withdrawn in 7) chap_capture_mark / _goto / _join, chap_bgrad_t, chap_wgrad_reduce_multi
+ *   7  the round-3 experiments that lost their whole-iteration A/B are gone from the ABI: capture points (graph branches / leaves on one
+ *      stream: +15-22 % step time), the "lazy gradient" chap_bgrad_t of chap_wgrad (+0.8 / +2.7 %), the deferred multi-layer slab reduction
+ *      (+-0 / +1 %); measurements in DESIGN.md section 5.  chap_conv_params.out2 / out2_from (a concat layer's input gradient as two dense
+ *      tensors), chap_conv_params.up (the x2 up-sampling gather fused into the conv's halo staging).
  */
 #ifndef CHAP_HIP_H
 #define CHAP_HIP_H
@@ -49,7 +53,7 @@
 extern "C" {
 #endif
 
-#define CHAP_ABI_VERSION 6
+#define CHAP_ABI_VERSION 7
 #define CHAP_STATS_MAX_SLOTS 1024  /* per-block partial slots of the BatchNorm statistics (one per persistent conv block) */
 #define CHAP_STATS_HDR 4           /* floats in front of the slots; word 0 = number of slots in use (int32)                */
 #define CHAP_ACT_BWD_SLOTS 1024    /* per-block partial slots of the BN-backward sums                                      */
@@ -181,32 +185,6 @@ int    chap_conv_c1_bwd(const chap_conv_c1_bwd_params* p, void* stream);
  * Partials are written per pixel-split to `ws` and reduced deterministically (no atomics) into
  * dw (+=) using element strides so the result lands in checkpoint layout.  Also db (+= sum_p B)
  * when requested (valid when B is the output gradient). */
-/* Optional "lazy gradient" (round 3): B is not read but COMPUTED while it is staged -- the apply phase of chap_act_bwd_* folded into the
- * weight gradient.  With dy != NULL the operand b describes the RAW conv output x and its forward transform (what chap_act_bwd_params.r
- * describes), and B[p][c] = g = gamma*invstd*(dz - S0/cnt - xhat*S1/cnt) with dz = dy * da/dz exactly as chap_act_bwd_apply computes it
- * (same fp32 operations, same bf16 rounding: bit-identical), from the totals row 0 of `sums` that chap_act_bwd_reduce left.  The blocks of the
- * first A-chunk also store g to `gout` ([pixels][Cb], dtype) for the input-gradient convolution that follows.  One incoming gradient, no pooled
- * gradient; training-mode BatchNorm only. */
-typedef struct {
-    const void*  dy;  int32_t dy_ld, dy_coff;   /* incoming gradient w.r.t. the activated value (dtype), on B's grid; NULL = feature off */
-    const float* sums;                           /* row 0 of the BN-backward workspace: S0[C] | S1[C]                                     */
-    const float* mean; const float* invstd; const float* gamma;
-    float        count;
-    void*        gout;                           /* g is also written here, or NULL                                                       */
-} chap_bgrad_t;
-
-/* Deferred slab reduction (round 3): with `deferred` != NULL chap_wgrad launches the partial-slab kernel only and fills *deferred (a HOST
- * struct) with what its reduction needs; chap_wgrad_reduce_multi then reduces the slabs of MANY layers in one launch (up to 16 per grid) -- the
- * weight gradients are not needed before the optimizer, so a backward pass issues one reduction at its end instead of one launch per layer on
- * its chain (73 / 110 per 2D / 3D iteration).  Same per-layer summation order as the immediate reduction: bit-identical.  The workspaces must
- * stay alive until chap_wgrad_reduce_multi has been enqueued. */
-typedef struct {
-    const float* ws; const float* ws_db; float* dw; float* db;
-    int64_t s_tap, s_kc, s_kn;
-    int32_t nsplit, taps, Ca, Cb, kc_valid, kn_valid;
-    int32_t nb_dw, nblocks, e4;            /* launch geometry of this entry's reduction (filled by chap_wgrad) */
-} chap_wgrad_reduce_entry;
-
 typedef struct {
     chap_src_t  a[2];          /* strided operand, up to two concatenated/added sources           */
     int32_t     na;  int32_t combine;
@@ -220,12 +198,9 @@ typedef struct {
     float*      db;            /* [Cb] += or NULL                                                 */
     void*       ws;  size_t ws_bytes;
     int32_t     dtype;
-    chap_bgrad_t bgrad;        /* B computed on the fly from (dy, b = raw x): see chap_bgrad_t; bgrad.dy == NULL: B is read from b */
-    chap_wgrad_reduce_entry* deferred;   /* host pointer or NULL: see chap_wgrad_reduce_entry */
 } chap_wgrad_params;
 size_t chap_wgrad_ws(const chap_wgrad_params* p);
 int    chap_wgrad(const chap_wgrad_params* p, void* stream);
-int    chap_wgrad_reduce_multi(const chap_wgrad_reduce_entry* entries_host, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm pieces (nn.BatchNorm2d/3d, unet.py:51,55; vnet.py:21,80,110).                    */
@@ -473,24 +448,6 @@ int chap_group_begin(void* stream);
 int chap_group_next_lane(void);
 int chap_group_end(void);
 int chap_group_cancel(void);   /* leave the region without issuing what was recorded (error paths of the caller) */
-
-/* ------------------------------------------------------------------------------------------
- * Capture points (ABI 6): parallel branches of a captured HIP graph on ONE stream.  The reference gets no concurrency between its two
- * decoders or between a layer's weight gradient and the rest of the backward chain (autograd issues them on one stream,
- * train_ours_2D.py:386 `loss.backward()`); here the iteration is one HIP graph whose shape the caller controls.  A capturing stream
- * has a dependency set -- the nodes the next captured launch depends on:
- *     chap_capture_mark(stream, slot, accumulate)   slot := (accumulate ? slot U : ) dependency set of `stream`
- *     chap_capture_goto(stream, slot)               dependency set := slot          (the next launches start a branch at the marked point)
- *     chap_capture_join(stream, slot)               dependency set U= slot; the slot is released
- * Two branches:   mark(F, 0); ...branch 1...; mark(T, 0); goto(F); ...branch 2...; join(T).
- * A leaf off a chain (a weight gradient nobody needs before the optimizer step):
- *                 mark(M, 0); ...leaf...; mark(LEAVES, 1); goto(M); ...the chain goes on...;   at the end   join(LEAVES).
- * Return 1 when applied, 0 when `stream` is not capturing (nothing to do: stream order stands), negative CHAP_E* on error.  The CALLER
- * must keep every buffer a branch touches alive (not hand it back to a stream-ordered allocator) until the join: inside the graph the
- * branches run concurrently, whatever the order they were captured in.  Slots: 0 .. 15, thread-local, valid within one capture. */
-int chap_capture_mark(void* stream, int32_t slot, int32_t accumulate);
-int chap_capture_goto(void* stream, int32_t slot);
-int chap_capture_join(void* stream, int32_t slot);
 
 /* Bandwidth calibration helper (tools/membw.py): grid-stride float4 copy with `blocks` blocks of 256. */
 int chap_debug_copy(const void* src, void* dst, int64_t bytes, int32_t blocks, void* stream);

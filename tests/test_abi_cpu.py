@@ -29,18 +29,17 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 35
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
-    assert lib.chap_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.chap_abi_version() == _lib.ABI_VERSION == 7
     # every entry point bound in the ctypes tables is declared in the header and vice versa
     bound = set(_lib._SIGS) | set(_lib._SIZE_FNS) | {"chap_last_error", "chap_abi_version", "chap_debug_copy", "chap_pack_describe", "chap_pack_multi",
-                                                                "chap_group_begin", "chap_group_next_lane", "chap_group_end", "chap_group_cancel", "chap_wgrad_reduce_multi",
-                                                                "chap_capture_mark", "chap_capture_goto", "chap_capture_join"}
+                                                                "chap_group_begin", "chap_group_next_lane", "chap_group_end", "chap_group_cancel"}
     assert bound == set(names), (bound ^ set(names))
 
 
 def test_ctypes_struct_sizes_match_header(tmp_path):
     """compile a tiny C program that prints sizeof() of every params struct and compare with ctypes."""
     from chap_amd import _lib
-    pairs = {"chap_src_t": _lib.Src, "chap_bgrad_t": _lib.Bgrad, "chap_wgrad_reduce_entry": _lib.WgradReduceEntry, "chap_conv_params": _lib.ConvParams, "chap_pack_params": _lib.PackParams,
+    pairs = {"chap_src_t": _lib.Src, "chap_conv_params": _lib.ConvParams, "chap_pack_params": _lib.PackParams,
              "chap_conv_c1_params": _lib.ConvC1Params, "chap_conv_c1_bwd_params": _lib.ConvC1BwdParams,
              "chap_wgrad_params": _lib.WgradParams, "chap_bn_finalize_params": _lib.BnFinalizeParams,
              "chap_bn_eval_params": _lib.BnEvalParams, "chap_act_bwd_params": _lib.ActBwdParams,
@@ -241,12 +240,16 @@ def test_group_region_state_machine_without_a_gpu():
     assert _lib.group.held is None
 
 
-def test_capture_point_arguments():
-    """chap_capture_* (ABI 6): slots are 0 .. 15; the binding's regions leave no holder behind when they are not capturing."""
+def test_capture_refuses_an_environment_the_runtime_dies_in():
+    """GPU_MAX_HW_QUEUES < 3: the first replay of the multi-stream graph aborts inside the runtime (profiles/r03_runtime_aborts.log); capture() raises
+    a ChapError up front instead (chap_amd.train.check_graph_environment), a single-stream step is let through."""
     from chap_amd import _lib
-    lib = _lib.lib()
-    for fn, args in (("chap_capture_mark", (None, 16, 0)), ("chap_capture_goto", (None, -1)), ("chap_capture_join", (None, 99))):
-        f = getattr(lib, fn)
-        f.restype, f.argtypes = ctypes.c_int, [ctypes.c_void_p] + [ctypes.c_int32] * (len(args) - 1)
-        assert f(*args) < 0 and b"out of range" in lib.chap_last_error()
-    assert _lib._holders == []
+    from chap_amd.train import check_graph_environment
+    check_graph_environment(True, {})
+    check_graph_environment(True, {"GPU_MAX_HW_QUEUES": "4"})
+    check_graph_environment(True, {"GPU_MAX_HW_QUEUES": "3"})
+    check_graph_environment(False, {"GPU_MAX_HW_QUEUES": "2"})
+    check_graph_environment(True, {"GPU_MAX_HW_QUEUES": "junk"})
+    for v in ("2", "1"):
+        with pytest.raises(_lib.ChapError, match="GPU_MAX_HW_QUEUES"):
+            check_graph_environment(True, {"GPU_MAX_HW_QUEUES": v})

@@ -340,81 +340,3 @@ def test_wgrad_conv3d_ragged(dtype, shape, cin, cout, add2, brick, monkeypatch):
     tol = 1e-4 if dtype == torch.float32 else 2e-2
     assert relerr(dw - 0.25, w.grad) < tol
     assert relerr(db, gy.sum((0, 2, 3, 4))) < tol
-
-
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("case", ["2d_16", "2d_64_cat", "3d_brick", "down"])
-def test_lazy_gradient_in_wgrad_equals_the_apply_launch(dtype, case):
-    """chap_bgrad_t (round 3): the apply phase of the BatchNorm / activation backward folded into the weight gradient's B staging.  g (written
-    by the weight gradient), dW and db are BIT-IDENTICAL to chap_act_bwd_apply followed by the plain chap_wgrad: same arithmetic
-    (csrc/actbwd_math.h), same rounding of g to the element type."""
-    from chap_amd import ops
-    from chap_amd.ops import Lazy
-    gen = torch.Generator().manual_seed(77)
-    dims, ks, st = 2, 3, 1
-    if case == "2d_16":
-        N, sp_in, cas, cb = 3, (1, 40, 52), [16], 16
-    elif case == "2d_64_cat":
-        N, sp_in, cas, cb = 2, (1, 24, 20), [32, 32], 64
-    elif case == "3d_brick":
-        N, sp_in, cas, cb, dims = 2, (8, 12, 20), [16], 16, 3
-    else:
-        N, sp_in, cas, cb, ks, st = 2, (1, 32, 48), [16], 32, 2, 2
-    sp = tuple(s // st if (dims == 3 or i > 0) else s for i, s in enumerate(sp_in))
-    mk = lambda c, sps: torch.randn((N,) + sps + (c,), generator=gen).to(DEV).to(dtype)     # noqa: E731
-    a_srcs = [Lazy(mk(c, sp_in), torch.rand(c, generator=gen).to(DEV) + 0.5, torch.randn(c, generator=gen).to(DEV) * 0.1, True, 0.01) for c in cas]
-    x = mk(cb, sp)                                                    # raw conv output
-    dy_full = mk(cb + 16, sp)                                         # the incoming gradient is a channel slice (coff = 8) of a wider tensor
-    scale, shift = torch.rand(cb, generator=gen).to(DEV) + 0.5, torch.randn(cb, generator=gen).to(DEV) * 0.2
-    keep = (torch.rand((N,) + sp + (cb,), generator=gen) > 0.2).to(torch.uint8).to(DEV) if dims == 2 else None
-    cm = None if dims == 2 else ((torch.rand(N, cb, generator=gen) > 0.5).float() * 2.0).to(DEV)
-    v = Lazy(x, scale, shift, True, 0.01, keep=keep, keep_scale=1.25, chan_mul=cm)
-    mean, invstd, gamma = torch.randn(cb, generator=gen).to(DEV) * 0.1, torch.rand(cb, generator=gen).to(DEV) + 0.5, torch.rand(cb, generator=gen).to(DEV) + 0.5
-    cnt = float(N * sp[0] * sp[1] * sp[2])
-    taps = ks ** dims
-    ca = sum(cas)
-
-    def run(fused):
-        dw, db = torch.zeros(cb, ca, taps, device=DEV), torch.zeros(cb, device=DEV)
-        dg, dbeta = torch.zeros(cb, device=DEV), torch.zeros(cb, device=DEV)
-        gout = torch.zeros((N,) + sp + (cb,), device=DEV, dtype=dtype)
-        sums = ops.act_bwd(v, [(dy_full, 8)], gout, mean=mean, invstd=invstd, gamma=gamma, dgamma=dg, dbeta=dbeta, count=cnt, bn_mode=1, apply=not fused)
-        bg = dict(dy=(dy_full, 8), sums=sums, mean=mean, invstd=invstd, gamma=gamma, count=cnt, gout=gout) if fused else None
-        ops.wgrad(a_srcs, v if fused else Lazy(gout), dw, (1, taps, ca * taps), grid=(N,) + sp, in_dims=sp_in, ksize=ks, stride=st, dims=dims, db=db, bgrad=bg)
-        torch.cuda.synchronize()
-        return gout, dw, db, dg, dbeta
-
-    a, b = run(False), run(True)
-    for name, t0, t1 in zip(("g", "dw", "db", "dgamma", "dbeta"), a, b):
-        assert torch.equal(t0, t1), (case, name, float((t0.float() - t1.float()).abs().max()))
-    assert a[0].float().abs().max() > 0 and a[1].abs().max() > 0
-
-
-def test_deferred_slab_reduction_equals_the_immediate_one():
-    """chap_wgrad(deferred=...) + chap_wgrad_reduce_multi: the slab reductions of several layers (few large slabs / many small ones, with and
-    without bias gradient, a padded head) in ONE launch give the bits of the per-layer reduction launches, and accumulate (+=) like them."""
-    from chap_amd import ops
-    from chap_amd.ops import Lazy
-    gen = torch.Generator().manual_seed(5)
-    layers = []
-    for (N, H, W, ca, cb, bias, knv) in ((12, 64, 64, 16, 16, True, 0), (2, 16, 16, 128, 64, True, 0), (3, 32, 32, 32, 32, False, 0), (2, 48, 48, 16, 16, True, 4)):
-        a = Lazy(torch.randn(N, 1, H, W, ca, generator=gen).to(DEV).to(torch.bfloat16))
-        b = Lazy(torch.randn(N, 1, H, W, cb, generator=gen).to(DEV).to(torch.bfloat16))
-        layers.append((a, b, ca, cb, bias, knv, (N, 1, H, W)))
-
-    def run(defer):
-        outs, lst = [], ([] if defer else None)
-        for a, b, ca, cb, bias, knv, grid in layers:
-            co = knv or cb
-            dw, db = torch.full((co, ca, 9), 0.5, device=DEV), (torch.full((co,), -1.0, device=DEV) if bias else None)
-            ops.wgrad([a], b, dw, (1, 9, ca * 9), grid=grid, in_dims=grid[1:], ksize=3, stride=1, dims=2, db=db, kn_valid=knv, defer=lst)
-            outs += [dw] + ([db] if bias else [])
-        if defer:
-            assert len(lst) == len(layers) and all(float(o.sum()) == o.numel() * (0.5 if o.dim() == 3 else -1.0) for o in outs)   # nothing reduced yet
-            ops.wgrad_reduce_multi(lst)
-            assert lst == []
-        torch.cuda.synchronize()
-        return outs
-
-    for x, y in zip(run(False), run(True)):
-        assert torch.equal(x, y)

@@ -483,54 +483,3 @@ def test_group_region_contract():
         with L.group(st):
             ops.sgd_step(p, torch.ones(64, device=DEV), m, lr, 0.9, 0.0)
     assert L.group.held is None                             # the region was left
-
-
-def test_capture_points_fork_and_join_on_one_stream():
-    """chap_capture_mark / _goto / _join (ABI 6): two long chains captured one after the other on ONE stream become parallel branches of the
-    graph; a leaf hangs off the chain and is joined at the end.  The replay equals the plain (serial) capture; outside a capture the calls
-    report "not capturing" and change nothing; a slot that was not marked in this capture is refused."""
-    from chap_amd import _lib as L
-    s = torch.cuda.Stream()
-    h = s.cuda_stream
-    assert L.capture_mark(h, 0) is False and L.capture_goto(h, 0) is False and L.capture_join(h, 0) is False        # not capturing
-    a0 = torch.randn(1 << 16, device=DEV)
-
-    def chain(x, k):
-        keep = []
-        for i in range(k):
-            x = x * 1.0001 + 0.5
-            keep.append(x)              # (nothing goes back to the allocator while the branches are being captured)
-        return x, keep
-
-    outs = {}
-    for dag in (False, True):
-        g = torch.cuda.CUDAGraph()
-        a = a0.clone()
-        with torch.cuda.graph(g, stream=s):
-            base = a * 2.0
-            if dag:
-                with pytest.raises(L.ChapError, match="not marked"):
-                    L.capture_goto(h, 5)
-                with L.leaves(h) as lv:
-                    assert lv.active
-                    with L.branches(h) as br:
-                        assert br.active
-                        b1, k1 = chain(base, 20)
-                        with lv.leaf():
-                            leaf = b1 * 7.0                 # nobody on the chains waits for it (elementwise: no allocator-managed workspace)
-                        br.next()
-                        b2, k2 = chain(base * 3.0, 20)
-                    out = b1 + b2
-                fin = out + leaf
-            else:
-                b1, k1 = chain(base, 20)
-                leaf = b1 * 7.0
-                b2, k2 = chain(base * 3.0, 20)
-                out = b1 + b2
-                fin = out + leaf
-        g.replay()
-        torch.cuda.synchronize()
-        outs[dag] = fin.clone()
-        del g
-    assert torch.equal(outs[True], outs[False])
-    assert L._holders == []

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out, overlap):
+def _worker(rank, world, port, out, overlap, bucket_bytes=None):
     sys.path.insert(0, ROOT)
     from chap_amd.parallel import DataParallelSync
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -20,7 +20,10 @@ def _worker(rank, world, port, out, overlap):
     n = 1003
     both = torch.zeros(2 * n)
     b0, b1 = both[:n], both[n:]         # bucket 0 = phase B (BCP) gradients, bucket 1 = phase V (VAT branch)
-    sync = DataParallelSync(both, dist, overlap=overlap)
+    sync = DataParallelSync(both, dist, overlap=overlap) if bucket_bytes is None else DataParallelSync(both, dist, overlap=overlap, bucket_bytes=bucket_bytes)
+    if bucket_bytes is not None:        # 1003 floats in pieces of 250: 250 + 250 + 250 + 250 + 3, contiguous and in order
+        ps = sync.pieces(b0)
+        assert [p.numel() for p in ps] == [250, 250, 250, 250, 3] and all(p.data_ptr() == b0.data_ptr() + 1000 * i for i, p in enumerate(ps))
     g = torch.Generator().manual_seed(100 + rank)
     b0 += torch.randn(n, generator=g)   # "BCP backward" finishes first ...
     sync.start_first()                  # ... its all-reduce starts while the VAT branch still runs (overlap schedule)
@@ -34,10 +37,11 @@ def _worker(rank, world, port, out, overlap):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("overlap", [True, False])
-def test_two_bucket_allreduce_gloo(tmp_path, overlap):
-    world, port = 2, 29000 + (os.getpid() + int(overlap)) % 2000
-    mp.spawn(_worker, args=(world, port, str(tmp_path), overlap), nprocs=world, join=True)
+@pytest.mark.parametrize("overlap,bucket_bytes", [(True, None), (False, None), (False, 1000), (True, 1000)])
+def test_two_bucket_allreduce_gloo(tmp_path, overlap, bucket_bytes):
+    """bucket_bytes = 1000: each gradient half goes out in five pieces (<= 16 MB pieces of the 49.4 MB 3D buffer) -- same sums."""
+    world, port = 2, 29000 + (os.getpid() + int(overlap) + (7 if bucket_bytes else 0)) % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path), overlap, bucket_bytes), nprocs=world, join=True)
     want = torch.zeros(1003)
     for r in range(world):
         g = torch.Generator().manual_seed(100 + r)

@@ -50,6 +50,62 @@ def test_one_rank_nccl_group_equals_the_plain_step(tmp_path, mode, overlap):
     assert torch.equal(ref["mom"], got["mom"])
 
 
+def test_one_rank_nccl_group_bucketed_3d_equals_the_plain_step(tmp_path):
+    """the 3D gradient buffer is exchanged in pieces of <= 16 MB.  Here the DualDecoder3d iteration (K = 2) through a 1-rank RCCL
+    group with the halves cut into 256 KB pieces (the small test net's 9.4 M-parameter half -> ~150 all-reduces), graph replay, fold schedule: bit
+    for bit the plain step, both buckets zeroed."""
+    port = 29650 + os.getpid() % 40
+    common = ["--out", tmp_path, "--mode", "graph", "--overlap", 0, "--net", "3d", "--vat-iters", 2]
+    _wait([_run(common + ["--no-dp"])])
+    _wait([_run(common + ["--port", port, "--bucket-bytes", 256 << 10])])
+    ref, got = torch.load(os.path.join(tmp_path, "rank0_graph_0_nodp_3d.pt")), torch.load(os.path.join(tmp_path, "rank0_graph_0_3d.pt"))
+    assert float(got["buckets"].abs().max()) == 0.0
+    for a, b in zip(got["losses"], ref["losses"]):
+        assert torch.equal(a, b)
+    assert not [k for k in ref["model"] if not torch.equal(ref["model"][k], got["model"][k])]
+    assert torch.equal(ref["mom"], got["mom"])
+
+
+def test_two_ranks_3d_k2_rehearsed_on_one_gpu(tmp_path):
+    """BASELINE config 4's data-parallel logic (DualDecoder3d, code/networks/vnet.py:225-238, K = 2 power iterations) with world 2: two rank processes
+    on cuda:0, gradient halves all-reduced through host memory (gloo) in 1 MB pieces, captured iteration.  Both ranks end with identical parameters
+    (BatchNorm running statistics stay per replica), equal to the oracle's mean-of-shard-gradients update."""
+    from oracle import init as oinit
+    from oracle import nets as onets
+    from oracle import train_step as ots
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dp_worker as W
+    port = 29850 + os.getpid() % 40
+    _wait([_run(["--rank", r, "--world", 2, "--out", tmp_path, "--mode", "graph", "--overlap", 0, "--port", port, "--backend", "gloo", "--net", "3d", "--vat-iters", 2,
+                 "--bucket-bytes", 1 << 20]) for r in range(2)])
+    r0, r1 = (torch.load(os.path.join(tmp_path, "rank%d_graph_0_3d.pt" % r)) for r in range(2))
+    assert float(r0["buckets"].abs().max()) == 0.0 and float(r1["buckets"].abs().max()) == 0.0
+    for k in r0["model"]:
+        if not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            assert torch.equal(r0["model"][k], r1["model"][k]), k
+    assert not torch.equal(r0["losses"][0], r1["losses"][0])          # the ranks did work on different shards
+    state = oinit.dual_decoder_3d_state(402)
+    grads = []
+    for r in range(2):
+        sd = {k: v.clone() for k, v in state.items()}
+        for k, v in sd.items():
+            if v.is_floating_point() and not k.endswith(("running_mean", "running_var")):
+                v.requires_grad_(True)
+        moms = {k: torch.zeros_like(v) for k, v in sd.items() if v.requires_grad}
+        vol, lab, inj, box = W.shard_inputs_3d(r, 2)
+        grads.append(ots.iteration(sd, moms, vol, lab, box, iter_num=W.IT0, lr=0.0, args=W.args_of("3d", 2), inject=inj, net=onets.dual_decoder_3d)["grads"])
+    num = den = 0.0
+    for k, g0 in grads[0].items():
+        g = (g0 + grads[1][k]) / 2.0
+        want = state[k] - 0.01 * (g + 1e-4 * state[k])
+        upd_o, upd_h = (want - state[k]).double(), (r0["model"][k] - state[k]).double()
+        num += float(((upd_o - upd_h) ** 2).sum())
+        den += float((upd_o ** 2).sum())
+    # 3D, K = 2 at this size is ill-conditioned: the fp32 oracle is itself 0.16 relative L2 from fp64 (profiles/r03_iteration_parity.jsonl, 3d_16x32x16_k2);
+    # the bound says "the mean of the two shard gradients", not "one shard's" (which is > 0.7 away)
+    assert (num / den) ** 0.5 < 0.35, (num / den) ** 0.5
+
+
 @pytest.mark.parametrize("backend", ["nccl", "gloo"])
 @pytest.mark.parametrize("mode", ["eager", "graph"])
 def test_two_ranks_hold_identical_parameters_equal_to_the_mean_of_shard_gradients(tmp_path, mode, backend):

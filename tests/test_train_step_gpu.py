@@ -320,11 +320,11 @@ def test_chapstep_streams_are_distinct():
 
 
 @pytest.mark.parametrize("dims", [2, 3])
-def test_lockstep_schedule_equals_the_stream_parallel_schedule(dims):
-    """Round 3: the iteration as three lockstep phases with grouped launches (ChapStep._iteration_lockstep, the default) against the
-    round-2 schedule (passes on three streams, one launch per op; args lockstep=False), from one state with the same injected
-    randomness: a grouped launch runs the same blocks on the same data as the separate launches, so losses, parameters,
-    BatchNorm buffers and momentum are equal BIT FOR BIT."""
+def test_grouped_decoder_launches_equal_separate_launches(dims, monkeypatch):
+    """Grouped launches (chap_hip.h, chap_group_*): in a captured iteration the passes that cannot fork a second stream (pass B, the early VAT
+    pass) run the same-shaped layers of their two decoders as ONE grid (CHAP_GROUP=1, the default) instead of back to back (CHAP_GROUP=0).  A
+    grouped grid runs the same blocks on the same data as the separate launches, so a replay of either graph and the eager step (decoders on two
+    streams) agree BIT FOR BIT: losses, parameters, BatchNorm buffers, momentum."""
     from chap_amd import _lib as L
     from chap_amd.networks import DualDecoder3d
     from tests.iteration_parity import inject_2d, inject_3d, to_dev
@@ -341,70 +341,27 @@ def test_lockstep_schedule_equals_the_stream_parallel_schedule(dims):
         inj = to_dev(inject_3d(B - lbs, lbs // 2 + (B - lbs) // 2, sp, 2), 3)
         mk, box, extra = (lambda: DualDecoder3d(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)), (2, 5, 3), {"num_classes": 2}
     res = {}
-    for lock in (True, False):
+    for mode in ("eager", "graph_grouped", "graph_separate"):
+        monkeypatch.setenv("CHAP_GROUP", "0" if mode == "graph_separate" else "1")
         m = mk().to(DEV).train()
         m.load_state_dict(state, strict=True)
-        step = ChapStep(m, dict(dict(labeled_bs=lbs, batch_size=B, vat_iters=2, lockstep=lock), **extra))
+        step = ChapStep(m, dict(dict(labeled_bs=lbs, batch_size=B, vat_iters=2), **extra))
         step.iter_num = 4500
         n0 = L.group.launched
-        out = step.step(vol.to(DEV), lab.to(DEV), box_yx=box, inject=inj)
-        torch.cuda.synchronize()
-        res[lock] = (out, {k: v.clone() for k, v in m.state_dict().items()}, step.opt.mom.clone(), L.group.launched - n0)
-    (oa, sa, ma, na), (ob, sb, mb, nb) = res[True], res[False]
-    for x, y in zip(oa["mix_losses"] + [oa["vat_loss"]], ob["mix_losses"] + [ob["vat_loss"]]):
-        assert torch.equal(x, y), (x, y)
-    assert [k for k in sa if not torch.equal(sa[k], sb[k])] == []
-    assert torch.equal(ma, mb)
-    assert na > 100                                         # grouped regions really ran (and far more of them than in the stream-parallel schedule)
-
-
-@pytest.mark.parametrize("dims", [2, 3])
-def test_graph_branches_and_leaves_equal_the_default_graph(dims, monkeypatch):
-    """Round 3, ABI 6: with CHAP_GROUP=3 the decoders of a captured pass that cannot fork a stream are parallel BRANCHES of the graph on the
-    one stream, with CHAP_WGRAD_LEAF=1 the weight gradients are LEAVES off the backward chain (chap_capture_mark / _goto / _join).  Only the
-    shape of the graph changes -- same kernels, same operands -- so a replay equals the default graph's and the eager step BIT FOR BIT
-    (a missing dependency or a buffer recycled between concurrent branches would show here).  Measured slower: optional."""
-    from chap_amd import _lib as L
-    from chap_amd.networks import DualDecoder3d
-    from tests.iteration_parity import inject_2d, inject_3d, to_dev
-    if dims == 2:
-        B, lbs, sp = 8, 4, (64, 64)
-        state = oinit.dual_decoder_2d_state(301)
-        vol, lab = ots.synthetic_batch(1337, lbs, B - lbs, *sp)
-        inj = to_dev(inject_2d(B - lbs, lbs // 2 + (B - lbs) // 2, sp[0], sp[1], 1), 2)
-        mk, box, extra = (lambda: DualDecoder(1, 4, {"decoder_type": "mcnet"})), (7, 11), {}
-    else:
-        B, lbs, sp = 4, 2, (16, 32, 16)
-        state = oinit.dual_decoder_3d_state(401)
-        vol, lab = ots.synthetic_batch_3d(1337, lbs, B - lbs, *sp)
-        inj = to_dev(inject_3d(B - lbs, lbs // 2 + (B - lbs) // 2, sp, 1), 3)
-        mk, box, extra = (lambda: DualDecoder3d(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)), (2, 5, 3), {"num_classes": 2}
-    marks = []
-    real_mark = L.capture_mark
-    monkeypatch.setattr(L, "capture_mark", lambda *a, **k: (marks.append(1), real_mark(*a, **k))[1])
-    res = {}
-    for mode in ("eager", "graph", "dag"):
-        monkeypatch.setenv("CHAP_GROUP", "3" if mode == "dag" else "1")
-        monkeypatch.setenv("CHAP_WGRAD_LEAF", "1" if mode == "dag" else "0")
-        m = mk().to(DEV).train()
-        m.load_state_dict(state, strict=True)
-        step = ChapStep(m, dict(dict(labeled_bs=lbs, batch_size=B, vat_iters=1), **extra))
-        step.iter_num = 4500
-        n0 = len(marks)
         if mode == "eager":
             out = step.step(vol.to(DEV), lab.to(DEV), box_yx=box, inject=inj)
         else:
             step.capture(vol.to(DEV), lab.to(DEV), warmup=1, inject=inj)
+            n0 = L.group.launched                           # (count the regions of the capture itself, not of its eager warm-up)
             out = step.replay(vol.to(DEV), lab.to(DEV), box_yx=box)
         torch.cuda.synchronize()
-        res[mode] = (out, {k: v.clone() for k, v in m.state_dict().items()}, step.opt.mom.clone(), len(marks) - n0)
-    for mode in ("graph", "dag"):
-        (oa, sa, ma, _), (ob, sb, mb, nb) = res["eager"], res[mode]
+        res[mode] = (out, {k: v.clone() for k, v in m.state_dict().items()}, step.opt.mom.clone(), L.group.launched - n0)
+    for mode in ("graph_grouped", "graph_separate"):
+        (oa, sa, ma, _), (ob, sb, mb, _) = res["eager"], res[mode]
         for x, y in zip(oa["mix_losses"] + [oa["vat_loss"]], ob["mix_losses"] + [ob["vat_loss"]]):
             assert torch.equal(x, y), (mode, x, y)
         assert [k for k in sa if not torch.equal(sa[k], sb[k])] == [], mode
         assert torch.equal(ma, mb), mode
-    assert res["graph"][3] == 0 and res["dag"][3] > 50      # the capture points were really used: two branch regions per forked pass, one leaf per weight gradient
 
 
 def test_staged_host_batches_equal_direct_replay():
