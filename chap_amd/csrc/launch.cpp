@@ -80,3 +80,36 @@ extern "C" int chap_group_cancel(void) {
     G.lanes.clear();
     return CHAP_OK;
 }
+
+#ifdef CHAP_TIMELINE
+// Lab only (see launch.h): slot bookkeeping of the untraced timeline.  Not declared in include/chap_hip.h -- the product library does not have it.
+#include <mutex>
+#include <string>
+namespace {
+struct tl_entry { std::string name; const void* fn; unsigned gx, gy, gz; void* stream; };
+std::mutex tl_mu;
+std::vector<tl_entry> tl_entries;
+unsigned long long* tl_buf = nullptr;
+long tl_cap = 0;
+}
+unsigned long long* chap_timeline_next_slot(const char* name, const void* fn, dim3 grid, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(tl_mu);
+    if (!tl_buf || (long)tl_entries.size() >= tl_cap) return nullptr;
+    tl_entries.push_back({name ? name : "?", fn, grid.x, grid.y, grid.z, (void*)s});
+    return tl_buf + 2 * (tl_entries.size() - 1);
+}
+extern "C" int chap_timeline_enable(void* buf, long nslots) {      // buf: device memory, 2 * nslots uint64; NULL switches the stamps off
+    std::lock_guard<std::mutex> lk(tl_mu);
+    tl_buf = (unsigned long long*)buf; tl_cap = nslots; tl_entries.clear();
+    return CHAP_OK;
+}
+extern "C" long chap_timeline_count(void) { std::lock_guard<std::mutex> lk(tl_mu); return (long)tl_entries.size(); }
+extern "C" int chap_timeline_entry(long i, char* name, int cap, unsigned* grid3, void** stream, const void** fn) {
+    std::lock_guard<std::mutex> lk(tl_mu);
+    if (i < 0 || i >= (long)tl_entries.size()) return CHAP_EINVAL;
+    const tl_entry& e = tl_entries[i];
+    snprintf(name, cap, "%s", e.name.c_str());
+    grid3[0] = e.gx; grid3[1] = e.gy; grid3[2] = e.gz; *stream = e.stream; *fn = e.fn;
+    return CHAP_OK;
+}
+#endif

@@ -14,19 +14,34 @@
 #include "common.h"
 
 constexpr int CHAP_MAX_GROUP = 4;
+// CHAP_TIMELINE (lab builds only, tools/lab/Makefile.lab -> tools/timeline_untraced.py): every launch behind the trampolines gets a slot of two
+// device words -- block (0, 0, 0) stores the 100 MHz s_memrealtime counter at its entry, every block atomicMax'es it at its exit -- so that the
+// CONCURRENT schedule of an untraced graph replay can be read back (a rocprofv3 kernel trace all but serialises the graph).  The slot pointer is
+// baked into the launch (and thus into the captured graph node); the product build has neither the field nor the stamps.
+#ifdef CHAP_TIMELINE
+template <typename A> struct chap_group { A p[CHAP_MAX_GROUP]; unsigned long long* tl; };
+unsigned long long* chap_timeline_next_slot(const char* name, const void* fn, dim3 grid, hipStream_t s);
+#define CHAP_TL_ENTER(G) do { if ((G).tl && threadIdx.x == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) (G).tl[0] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CHAP_TL_EXIT(G) do { if ((G).tl && threadIdx.x == 0) (void)atomicMax((G).tl + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+#else
 template <typename A> struct chap_group { A p[CHAP_MAX_GROUP]; };
+#define CHAP_TL_ENTER(G) do {} while (0)
+#define CHAP_TL_EXIT(G) do {} while (0)
+#endif
 
 // group index of this block: gridDim.z = groups x base_z (base_z = the kernel's own grid.z, 1 for all but the weight gradient)
 __device__ __forceinline__ int chap_group_index(int base_z = 1) { return base_z == 1 ? (int)blockIdx.z : (int)blockIdx.z / base_z; }
 
 template <typename A, void (*BODY)(const A&), int MAXT, int MINW>
-__global__ __launch_bounds__(MAXT, MINW) void chap_grouped(const chap_group<A> G) { BODY(G.p[blockIdx.z]); }
+__global__ __launch_bounds__(MAXT, MINW) void chap_grouped(const chap_group<A> G) { CHAP_TL_ENTER(G); BODY(G.p[blockIdx.z]); CHAP_TL_EXIT(G); }
 // kernels whose own grid uses z (the weight gradient): the body finds its group from A::base_z
 template <typename A, void (*BODY)(const A&, int), int MAXT, int MINW>
 __global__ __launch_bounds__(MAXT, MINW) void chap_grouped_z(const chap_group<A> G) {
     const int bz = G.p[0].base_z;
     const int grp = (int)blockIdx.z / bz;
+    CHAP_TL_ENTER(G);
     BODY(G.p[grp], (int)blockIdx.z - grp * bz);
+    CHAP_TL_EXIT(G);
 }
 
 struct chap_pending {
@@ -46,6 +61,9 @@ static int chap_launch_merged(const chap_pending* const* items, int n, hipStream
     for (int i = 0; i < CHAP_MAX_GROUP; ++i) memcpy(&g.p[i], items[i < n ? i : 0]->arg, sizeof(A));
     dim3 grid = items[0]->grid;
     grid.z *= (unsigned)n;
+#ifdef CHAP_TIMELINE
+    g.tl = chap_timeline_next_slot(items[0]->name, items[0]->fn, grid, s);
+#endif
     void* args[] = {&g};
     const hipError_t e = hipLaunchKernel(items[0]->fn, grid, items[0]->block, args, items[0]->lds, s);
     if (e != hipSuccess) { (void)hipGetLastError(); chap_set_error("%s: launch failed: %s", items[0]->name, hipGetErrorString(e)); return CHAP_ELAUNCH; }
