@@ -16,9 +16,16 @@ void chap_set_error(const char* fmt, ...);
 bool chap_group_recording();      // launch.h: true between chap_group_begin() and chap_group_end()
 // after a DIRECT launch (kernels that are not behind launch.h's trampoline): inside a group region it would have overtaken the
 // recorded launches, which is an error of the caller
+#ifdef CHAP_TIMELINE      // lab builds only (launch.h): a one-thread marker kernel behind every direct launch stamps the time its stream got past it
+void chap_timeline_mark(const char* name, void* stream);
+#define CHAP_TL_MARK(name) chap_timeline_mark(name, (void*)stream)
+#else
+#define CHAP_TL_MARK(name) do {} while (0)
+#endif
 #define CHAP_LAUNCH_CHECK(name) do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
     chap_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return CHAP_ELAUNCH; } \
-    if (chap_group_recording()) { chap_set_error("%s: not allowed between chap_group_begin() and chap_group_end()", name); return CHAP_EUNSUPPORTED; } } while (0)
+    if (chap_group_recording()) { chap_set_error("%s: not allowed between chap_group_begin() and chap_group_end()", name); return CHAP_EUNSUPPORTED; } \
+    CHAP_TL_MARK(name); } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {

@@ -16,6 +16,13 @@
 #pragma once
 #include "conv_kernel.h"
 
+#ifdef CHAP_CONV_TRACE         // lab only (tools/lab/conv_lab.hip p): phase stamps of every wave of four blocks
+__device__ unsigned long long chap_trace_k[4][4][16];
+#define CHAP_KSTAMP(k) do { if ((threadIdx.x & 63) == 0 && blockIdx.y == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 4) chap_trace_k[blockIdx.x / 97][threadIdx.x >> 6][k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CHAP_KSTAMP(k) do {} while (0)
+#endif
+
 template <typename T, bool D3, int KC, int CPAR>
 __host__ __device__ constexpr size_t conv_kpar_lds_bytes(int NT) {
     typedef conv_geom<3, 1, D3, D3 ? 1 : 2> G;
@@ -36,6 +43,7 @@ __device__ __forceinline__ void conv_kpar_kernel(const chap_conv_params& P) {   
     constexpr size_t HB = (size_t)G::HP * PS + HALO_DUMMY;      // elements per halo buffer
     static_assert(sizeof(T) == 2 && (CPAR == 2 || CPAR == 4) && ROWS % 4 == 0, "conv_kpar: bf16, 2 or 4 chunks side by side");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    CHAP_KSTAMP(0);
     T* halo = (T*)smem;
     f32x4* red = (f32x4*)smem;                                  // [wave][RW][NT][64 lanes], after the tap loops
     constexpr size_t HALOS = CPAR * HB * sizeof(T), RED = (size_t)4 * RW * NT * 64 * sizeof(f32x4);
@@ -101,6 +109,7 @@ __device__ __forceinline__ void conv_kpar_kernel(const chap_conv_params& P) {   
 #pragma unroll
     for (int t = 0; t < NT; ++t) ooff[t] = px * P.out_ld + P.out_coff + (nt0 + t) * 16 + 4 * g;
 
+    CHAP_KSTAMP(1);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int n, z0, y0, x0;
         tile_coords<G::TH, G::TW, 1>(tile, tiles_x, tiles_y, P.D, n, z0, y0, x0);
@@ -121,11 +130,15 @@ __device__ __forceinline__ void conv_kpar_kernel(const chap_conv_params& P) {   
 #pragma unroll
                 for (int t = 0; t < NT; ++t) wf[t] = frag<T>::load(wc_g + (long)step * wstep + (nt0 + t < ntiles_total ? t : 0) * 512);   // clamped: those channels are never stored
             };
+            CHAP_KSTAMP(2);
             __syncthreads();                                    // the LDS buffers are free (previous round's tap loops / previous tile's reduction; first: the scale/shift cache is written)
+            CHAP_KSTAMP(3);
 #pragma unroll
             for (int c = 0; c < CPAR; ++c)
                 halo_commit<T, KC, false, UNITS, !D3, ONE>(R[c], U, halo + c * HB, s0, s1, aff, plain, n, r * CPAR + c, false);
+            CHAP_KSTAMP(4);
             __syncthreads();
+            CHAP_KSTAMP(5);
             // ---- tap loop of chunk r*CPAR + ck over this wave's RW rows; weight fragments stream from L2 two steps ahead
             const T* hb = halo + ck * HB + (size_t)(rgrp * RW) * (ST * G::HW * PS);
             auto load_x = [&](int step, F (&xf)[RW]) __attribute__((always_inline)) {
@@ -153,12 +166,15 @@ __device__ __forceinline__ void conv_kpar_kernel(const chap_conv_params& P) {   
             }
         }
         // ---- the CPAR partial sums of every row meet in LDS; wave f finishes rows [f*FR, f*FR + FR)
+        CHAP_KSTAMP(6);
         __syncthreads();                                        // every wave is done reading the halos
+        CHAP_KSTAMP(7);
 #pragma unroll
         for (int m = 0; m < RW; ++m)
 #pragma unroll
             for (int t = 0; t < NT; ++t) red[((wave * RW + m) * NT + t) * 64 + lane] = acc[m][t];
         __syncthreads();
+        CHAP_KSTAMP(8);
         const bool xok = x0 + px < P.W;
         const long o0 = ((((long)n * P.D + z0) * P.H + y0) * P.W + x0) * P.out_ld;
         char* ob = (char*)P.out + o0 * (P.out_f32 ? 4 : (long)sizeof(T));
@@ -189,6 +205,7 @@ __device__ __forceinline__ void conv_kpar_kernel(const chap_conv_params& P) {   
             }
         }
     }
+    CHAP_KSTAMP(9);
     // ---- BatchNorm statistics: this block's partial slot (conv_fwd_kernel's layout and order)
     if (do_stats) {
         __syncthreads();
@@ -213,4 +230,5 @@ __device__ __forceinline__ void conv_kpar_kernel(const chap_conv_params& P) {   
             if (nl < P.Cout) st[which * P.Cout + nl] = v;
         }
     }
+    CHAP_KSTAMP(10);
 }

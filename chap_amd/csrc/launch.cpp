@@ -63,7 +63,7 @@ extern "C" int chap_group_end(void) {
             int n = 0;
             grp[n++] = items[i];
             used[i] = 1;
-            for (size_t k = i + 1; k < items.size() && n < CHAP_MAX_GROUP; ++k)
+            for (size_t k = i + 1; k < items.size() && n < CHAP_MAX_LANES; ++k)
                 if (!used[k] && same_launch(*items[i], *items[k])) { grp[n++] = items[k]; used[k] = 1; }
             rc = items[i]->merged(grp, n, G.stream);
             ++launched;
@@ -82,34 +82,49 @@ extern "C" int chap_group_cancel(void) {
 }
 
 #ifdef CHAP_TIMELINE
-// Lab only (see launch.h): slot bookkeeping of the untraced timeline.  Not declared in include/chap_hip.h -- the product library does not have it.
+// Lab only (see launch.h): bookkeeping of the untraced timeline.  Not declared in include/chap_hip.h -- the product library does not have it.
 #include <mutex>
 #include <string>
 namespace {
-struct tl_entry { std::string name; const void* fn; unsigned gx, gy, gz; void* stream; };
+struct tl_entry { std::string name; const void* fn; unsigned gx, gy, gz; void* stream; long first; };      // first: index of the launch's first (start, end) pair
 std::mutex tl_mu;
 std::vector<tl_entry> tl_entries;
 unsigned long long* tl_buf = nullptr;
-long tl_cap = 0;
+long tl_cap = 0, tl_used = 0;          // in (start, end) pairs
 }
 unsigned long long* chap_timeline_next_slot(const char* name, const void* fn, dim3 grid, hipStream_t s) {
     std::lock_guard<std::mutex> lk(tl_mu);
-    if (!tl_buf || (long)tl_entries.size() >= tl_cap) return nullptr;
-    tl_entries.push_back({name ? name : "?", fn, grid.x, grid.y, grid.z, (void*)s});
-    return tl_buf + 2 * (tl_entries.size() - 1);
+    const long nb = 3;                  // first / middle / last block
+    if (!tl_buf || tl_used + nb > tl_cap) return nullptr;
+    tl_entries.push_back({name ? name : "?", fn, grid.x, grid.y, grid.z, (void*)s, tl_used});
+    tl_used += nb;
+    return tl_buf + 2 * tl_entries.back().first;
 }
-extern "C" int chap_timeline_enable(void* buf, long nslots) {      // buf: device memory, 2 * nslots uint64; NULL switches the stamps off
+__global__ void chap_tl_marker_kernel(unsigned long long* p) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); p[0] = t; p[1] = t; }
+void chap_timeline_mark(const char* name, void* stream) {
+    unsigned long long* p = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(tl_mu);
+        if (!tl_buf || tl_used + 3 > tl_cap) return;
+        tl_entries.push_back({std::string(name ? name : "?") + " (end marker)", nullptr, 1, 1, 1, stream, tl_used});
+        tl_used += 3;
+        p = tl_buf + 2 * tl_entries.back().first;
+    }
+    hipLaunchKernelGGL(chap_tl_marker_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, p);
+    (void)hipGetLastError();
+}
+extern "C" int chap_timeline_enable(void* buf, long npairs) {      // buf: device memory, 2 * npairs uint64; NULL switches the stamps off
     std::lock_guard<std::mutex> lk(tl_mu);
-    tl_buf = (unsigned long long*)buf; tl_cap = nslots; tl_entries.clear();
+    tl_buf = (unsigned long long*)buf; tl_cap = npairs; tl_used = 0; tl_entries.clear();
     return CHAP_OK;
 }
 extern "C" long chap_timeline_count(void) { std::lock_guard<std::mutex> lk(tl_mu); return (long)tl_entries.size(); }
-extern "C" int chap_timeline_entry(long i, char* name, int cap, unsigned* grid3, void** stream, const void** fn) {
+extern "C" int chap_timeline_entry(long i, char* name, int cap, unsigned* grid3, void** stream, const void** fn, long* first) {
     std::lock_guard<std::mutex> lk(tl_mu);
     if (i < 0 || i >= (long)tl_entries.size()) return CHAP_EINVAL;
     const tl_entry& e = tl_entries[i];
     snprintf(name, cap, "%s", e.name.c_str());
-    grid3[0] = e.gx; grid3[1] = e.gy; grid3[2] = e.gz; *stream = e.stream; *fn = e.fn;
+    grid3[0] = e.gx; grid3[1] = e.gy; grid3[2] = e.gz; *stream = e.stream; *fn = e.fn; *first = e.first;
     return CHAP_OK;
 }
 #endif

@@ -13,16 +13,40 @@
 #include <type_traits>
 #include "common.h"
 
-constexpr int CHAP_MAX_GROUP = 4;
-// CHAP_TIMELINE (lab builds only, tools/lab/Makefile.lab -> tools/timeline_untraced.py): every launch behind the trampolines gets a slot of two
-// device words -- block (0, 0, 0) stores the 100 MHz s_memrealtime counter at its entry, every block atomicMax'es it at its exit -- so that the
-// CONCURRENT schedule of an untraced graph replay can be read back (a rocprofv3 kernel trace all but serialises the graph).  The slot pointer is
-// baked into the launch (and thus into the captured graph node); the product build has neither the field nor the stamps.
+#ifndef CHAP_MAX_GROUP_N
+#define CHAP_MAX_GROUP_N 4
+#endif
+constexpr int CHAP_MAX_GROUP = CHAP_MAX_GROUP_N;
 #ifdef CHAP_TIMELINE
-template <typename A> struct chap_group { A p[CHAP_MAX_GROUP]; unsigned long long* tl; };
+constexpr int CHAP_MAX_LANES = CHAP_MAX_GROUP - 1;      // lanes merged into one grid (lab builds: the last argument block carries the timeline pointer)
+#else
+constexpr int CHAP_MAX_LANES = CHAP_MAX_GROUP;
+#endif
+// CHAP_TIMELINE (lab builds only, chap_amd/csrc/Makefile.lab -> tools/timeline_untraced.py): every launch behind the trampolines gets three
+// (start, end) pairs: its first, middle and last block (linear block id 0, n / 2, n - 1) store the 100 MHz s_memrealtime counter at their entry and
+// exit, plain stores to their own words, so that the CONCURRENT schedule of an untraced graph replay can be read back (a rocprofv3 kernel trace all
+// but serialises the graph).  Stamping EVERY block perturbs the step too much: one atomicMax per block on a per-launch word +42 %, a plain store pair
+// per block +26 % (the scalar clock read at a block's entry sits in front of its first kernel-argument load); three blocks per launch: see
+// profiles/r04_timeline_untraced_*.json for the measured overhead.  A kernel's interval is [min start, max end] of the three (persistent grids end
+// together; in a multi-round grid the last block id is dispatched last).  The pointer is baked into the launch (and thus into the captured graph
+// node); the product build has neither the field nor the stamps.  The directly launched kernels (losses, largest-CC, VAT helpers, SGD) are followed
+// by a one-thread marker kernel on their stream (CHAP_TL_MARK in CHAP_LAUNCH_CHECK, common.h): its time stamp bounds their end.
+// The pointer travels in the LAST 8 BYTES of the argument block of lane 3 (lab builds merge at most 3 lanes): the kernel-argument size stays what
+// the product build has (a first version with an extra field made every kernel of the lab build slower -- 8.4 vs 6.75 ms per 2D step with the
+// stamps switched OFF: the conv's argument block crossed 1 KB).
+#ifdef CHAP_TIMELINE
+template <typename A> struct chap_group { A p[CHAP_MAX_GROUP]; };
+#define CHAP_TL_PTR(G) (*(unsigned long long* const*)((const char*)&(G) + sizeof(G) - 8))
 unsigned long long* chap_timeline_next_slot(const char* name, const void* fn, dim3 grid, hipStream_t s);
-#define CHAP_TL_ENTER(G) do { if ((G).tl && threadIdx.x == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) (G).tl[0] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define CHAP_TL_EXIT(G) do { if ((G).tl && threadIdx.x == 0) (void)atomicMax((G).tl + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime()); } while (0)
+__device__ __forceinline__ int chap_tl_pair() {      // 0 / 1 / 2 for the first / middle / last block of the grid, -1 for every other block
+    if (threadIdx.x != 0) return -1;
+    const unsigned long nb = (unsigned long)gridDim.x * gridDim.y * gridDim.z;
+    const unsigned long b = (unsigned long)blockIdx.x + (unsigned long)gridDim.x * ((unsigned long)blockIdx.y + (unsigned long)gridDim.y * blockIdx.z);
+    return b == 0 ? 0 : (b == nb - 1 ? 2 : (b == nb / 2 ? 1 : -1));
+}
+#define CHAP_TL_ENTER(G) unsigned long long* const chap_tl_p = CHAP_TL_PTR(G); const int chap_tl_k = chap_tl_p ? chap_tl_pair() : -1; \
+    do { if (chap_tl_k >= 0) chap_tl_p[2 * chap_tl_k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CHAP_TL_EXIT(G) do { if (chap_tl_k >= 0) chap_tl_p[2 * chap_tl_k + 1] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 template <typename A> struct chap_group { A p[CHAP_MAX_GROUP]; };
 #define CHAP_TL_ENTER(G) do {} while (0)
@@ -62,7 +86,10 @@ static int chap_launch_merged(const chap_pending* const* items, int n, hipStream
     dim3 grid = items[0]->grid;
     grid.z *= (unsigned)n;
 #ifdef CHAP_TIMELINE
-    g.tl = chap_timeline_next_slot(items[0]->name, items[0]->fn, grid, s);
+    {   // (lane 3 is never a real lane in a lab build: chap_group_end merges at most CHAP_MAX_LANES = 3)
+        unsigned long long* tl = chap_timeline_next_slot(items[0]->name, items[0]->fn, grid, s);
+        memcpy((char*)&g + sizeof(g) - 8, &tl, 8);
+    }
 #endif
     void* args[] = {&g};
     const hipError_t e = hipLaunchKernel(items[0]->fn, grid, items[0]->block, args, items[0]->lds, s);

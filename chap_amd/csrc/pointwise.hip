@@ -342,6 +342,9 @@ __device__ __forceinline__ void act_pool2_kernel(const chap_pool_params& P) {
 extern "C" int chap_act_pool2(const chap_pool_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->r.ptr && p->out, "chap_act_pool2: null argument");
     CHAP_CHECK_ARG(p->r.C % 8 == 0 && p->H % 2 == 0 && p->W % 2 == 0 && (p->D <= 1 || p->D % 2 == 0), "chap_act_pool2: C%%8, even dims required");
+#ifdef CHAP_LAB      // lab builds only: timing bound (wrong numerics) of fusing this launch into its consumer
+    { static int skip = -1; if (skip < 0) skip = getenv("CHAP_LAB_SKIP_POOL") ? 1 : 0; if (skip) return CHAP_OK; }
+#endif
     const long total = (long)p->N * (p->D > 1 ? p->D / 2 : 1) * (p->H / 2) * (p->W / 2) * (p->r.C / 8);
     const int blocks = chap_blocks(total, 4096);
     if (p->dtype == CHAP_BF16) return chap_launch<chap_pool_params, act_pool2_kernel<bf16_t>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_act_pool2");
@@ -460,6 +463,9 @@ __device__ __forceinline__ void upsample2x_cell_kernel(const chap_upsample_param
 extern "C" int chap_upsample2x(const chap_upsample_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->r.ptr && p->out && p->r.C % 8 == 0, "chap_upsample2x: bad argument");
     CHAP_CHECK_ARG(p->out_ld % 8 == 0 && p->out_coff % 8 == 0, "chap_upsample2x: out_ld/out_coff must be multiples of 8");
+#ifdef CHAP_LAB      // lab builds only: timing bound (wrong numerics) of fusing this launch into its consumer
+    { static int skip = -1; if (skip < 0) skip = getenv("CHAP_LAB_SKIP_UPSAMPLE") ? 1 : 0; if (skip) return CHAP_OK; }
+#endif
     const bool d3 = p->dims == 3;
     if (p->H >= 2 && p->W >= 2 && (!d3 || p->D >= 2)) {
         const long cells = (long)p->N * (d3 ? p->D - 1 : p->D) * (p->H - 1) * (p->W - 1) * (p->r.C / 8);
@@ -545,6 +551,9 @@ __device__ __forceinline__ void upsample2x_bwd_kernel(const chap_upsample_bwd_pa
 }
 extern "C" int chap_upsample2x_bwd(const chap_upsample_bwd_params* p, void* stream) {
     CHAP_CHECK_ARG(p && p->g && p->out && p->C % 8 == 0 && p->g_ld % 8 == 0 && p->g_coff % 8 == 0, "chap_upsample2x_bwd: bad argument");
+#ifdef CHAP_LAB      // lab builds only: timing bound (wrong numerics) of fusing this launch into its consumer
+    { static int skip = -1; if (skip < 0) skip = getenv("CHAP_LAB_SKIP_UPSAMPLE_BWD") ? 1 : 0; if (skip) return CHAP_OK; }
+#endif
     const long total = (long)p->N * p->D * p->H * p->W * (p->C / 8);
     const int blocks = chap_blocks(total, 8192);
     if (p->dtype == CHAP_BF16) return chap_launch<chap_upsample_bwd_params, upsample2x_bwd_kernel<bf16_t>, 256>(dim3(blocks), dim3(256), 0, (hipStream_t)stream, *p, "chap_upsample2x_bwd");

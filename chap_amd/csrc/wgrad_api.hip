@@ -28,15 +28,24 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
         if (p->dims == 3 && p->ksize == 3 && p->stride == 1 && p->dtype == CHAP_BF16 && min_bricks > 0 && bricks >= min_bricks &&
             p->a[0].C <= 256 && (p->na < 2 || p->a[1].C <= 256) && p->b.C <= 256) { q->brick = 1; q->KC = 16; }      // (<= 256 channels per source: the brick kernels' scale/shift cache)
     }
+    // 2D 3x3 layers on large images, bf16: wave-private pipelines (wgrad_wp.h; brick == 2), 16-channel A chunks.  CHAP_WGRAD_WP (lab knob): 0 = never,
+    // N = from N tiles (8 x 16 pixels) up.
+    {
+        const char* e = getenv("CHAP_WGRAD_WP");        // (read per call: the tests force the kernel onto small ragged grids)
+        const long wp_min = e ? atol(e) : 1024;
+        const long t8 = (long)p->N * cdiv(p->H, 8) * cdiv(p->W, 16);
+        if (p->dims == 2 && p->ksize == 3 && p->stride == 1 && p->combine == 0 && p->dtype == CHAP_BF16 && wp_min > 0 && t8 >= wp_min &&
+            p->a[0].C <= 128 && p->a[0].C % 16 == 0 && (p->na < 2 || (p->a[1].C <= 128 && p->a[1].C % 16 == 0)) && p->b.C <= 128) { q->brick = 2; q->KC = 16; }
+    }
     // (tried: 16 x 16 tiles for the 2D 16-channel levels -- 16->16 at 256x256 35.8 -> 32.9 us with 512 blocks, 16+16->16 unchanged: not kept)
     CHAP_CHECK_ARG(q->Ca % q->KC == 0, "chap_wgrad: Ca=%d not a multiple of %d", q->Ca, q->KC);
     q->taps = p->ksize * p->ksize * (p->dims == 3 ? p->ksize : 1);
     const bool small_tile = (p->dims == 3 && p->ksize >= 2);   // 3D geometries use 4 x 16 tiles (MR = 1)
     const int TH = small_tile ? 4 : 8;
-    q->ntiles = (long)p->N * (q->brick ? cdiv(p->D, 4) : p->D) * cdiv(p->H, TH) * cdiv(p->W, 16);
+    q->ntiles = (long)p->N * (q->brick == 1 ? cdiv(p->D, 4) : p->D) * cdiv(p->H, TH) * cdiv(p->W, 16);
     static int bn16_maxc = -1;
     if (bn16_maxc < 0) { const char* e = getenv("CHAP_WGRAD_BN16_MAXC"); bn16_maxc = (e && atoi(e) > 0) ? atoi(e) : 16; }      // lab knob (wgrad_dispatch.inc reads it alike)
-    const int bn = (q->Cb <= 16 || (q->brick && q->Cb <= bn16_maxc)) ? 16 : 32;
+    const int bn = (q->Cb <= 16 || (q->brick == 1 && q->Cb <= bn16_maxc)) ? 16 : 32;
     const long pairs = (long)(q->Ca / q->KC) * cdiv(q->Cb, bn);
     // Persistent, pipelined blocks.  What bounds the small-channel layers (most of the bytes) is memory-level parallelism --
     // a block keeps a few KB in flight -- so they take as many blocks as stay resident (LDS: 3 per CU with 16-channel chunks,
@@ -49,6 +58,7 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     const bool d3 = p->dims == 3;
     const char* env = getenv("CHAP_WGRAD_BLOCKS");          // lab knob for those sweeps
     if (env && atol(env) > 0) target = atol(env);
+    else if (q->brick == 2) { static long wpb = -1; if (wpb < 0) { const char* e = getenv("CHAP_WGRAD_WP_BLOCKS"); wpb = (e && atol(e) > 0) ? atol(e) : 512; } target = wpb; }
     else if (p->ksize == 2) target = 256;
     else if (q->brick) { const char* eb2 = getenv("CHAP_WGRAD_BRICK_BLOCKS"); target = bn == 16 ? 512 : (eb2 && atol(eb2) > 0 ? atol(eb2) : 256); }      // 16-wide B tiles leave LDS for two bricks per CU (3D 16->16 at 112x112x80: 88 / 66 / 85 us with 256 / 512 / 768 blocks)
     else if (q->KC == 16) target = d3 ? 512 : 768;
@@ -57,7 +67,7 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
     {   // lab knob: CHAP_WGRAD_TARGETS="a,b,c" = split targets of (2D 16-channel chunks, 2D two-source / <= 32 channels, everything else k3/k1)
         const char* et = getenv("CHAP_WGRAD_TARGETS");
         long ta = 0, tb = 0, tc = 0;
-        if (et && !(env && atol(env) > 0) && sscanf(et, "%ld,%ld,%ld", &ta, &tb, &tc) == 3 && p->ksize != 2 && !q->brick) {
+        if (et && !(env && atol(env) > 0) && sscanf(et, "%ld,%ld,%ld", &ta, &tb, &tc) == 3 && p->ksize != 2 && !q->brick) {      // (brick: 3D bricks = 1, wave-private 2D = 2)
             if (q->KC == 16) { if (!d3 && ta > 0) target = ta; }
             else if (!d3 && (p->na == 2 || q->Ca <= 32)) { if (tb > 0) target = tb; }      // (the class that used to have its own default)
             else if (tc > 0) target = tc;

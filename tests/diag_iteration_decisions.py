@@ -173,6 +173,65 @@ def decisions_diff(a, b):
     return out
 
 
+def stage_errors(state, vol, inj, U, xi=10.0):
+    """The first power-iteration pass (forward on x + xi d, distance to FIXED targets, backward to the input) stage by stage: relative L2 distance
+    to the fp64 oracle of (a) the five encoder features, (b) the logits, (c) d(distance)/d(logits), (d) the input gradient, for the HIP fp32 path and
+    for the fp32 oracle -- which stage makes the HIP path's VAT direction noisier than the CPU fp32 arithmetic, if any.  The soft targets are
+    the fp64 oracle's on every side (they only set the scale of the cancellation q - p)."""
+    x = vol[-U:].contiguous()
+    d0 = inj["d0"]
+
+    def oracle(dtype):
+        sd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in state.items()}
+        with torch.no_grad():
+            t1, t2 = onets.dual_decoder_2d(sd, x.to(dtype), train=True, drop=inj["drop_A"], update_stats=False)
+            soft = (torch.softmax(t1, 1), torch.softmax(t2, 1))
+        d = ots.l2_normalize(d0.to(dtype))
+        xh = (x.to(dtype) + xi * d).requires_grad_(True)
+        l1, l2, feats = onets.dual_decoder_2d(sd, xh, train=True, drop=inj["drop_V0"], update_stats=False, with_feat=True)
+        return sd, soft, xh, (l1, l2), feats
+
+    sd64, soft64, xh64, lg64, f64 = oracle(torch.float64)
+    out = {}
+    ref = None
+    for tag, dtype in (("o64", torch.float64), ("o32", torch.float32)):
+        sd, _, xh, (l1, l2), feats = (sd64, soft64, xh64, lg64, f64) if tag == "o64" else oracle(dtype)
+        soft = tuple(t.to(dtype) for t in soft64)
+        dist = ots.kl_two_heads((l1, l2), soft)
+        g1, g2, dx = torch.autograd.grad(dist, [l1, l2, xh])
+        out[tag] = dict(feats=[f.detach().double() for f in feats], logits=[l1.detach().double(), l2.detach().double()], dlogits=[g1.double(), g2.double()], dx=dx.double())
+    # HIP
+    m = DualDecoder(1, 4, {"decoder_type": "mcnet"}).to(DEV).train()
+    m.load_state_dict(state, strict=True)
+    injd = to_dev(inj, 2)
+    xd = x.to(DEV)
+    d = torch.empty_like(xd)
+    ops.l2_normalize(injd["d0"], d)
+    xh = torch.empty_like(xd).requires_grad_(True)
+    ops.perturb(xd, d, xh, xi)
+    with m.frozen():
+        l1, l2, feats = m(xh, True, update_stats=False, drop_masks=injd["drop_V0"])
+    g1, g2 = torch.empty_like(l1), torch.empty_like(l2)
+    ops.kl_fwd_bwd((l1, l2), tuple(t.float().to(DEV) for t in soft64), None, (g1, g2))
+    dx = m.backward_saved(l1, [g1, g2], need_wgrad=False, need_dx=True)
+    torch.cuda.synchronize()
+    out["hip"] = dict(feats=[f.detach().double().cpu() for f in feats], logits=[l1.detach().double().cpu(), l2.detach().double().cpu()],
+                      dlogits=[g1.double().cpu(), g2.double().cpu()], dx=dx.double().cpu())
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-300))
+
+    res = {}
+    for side in ("hip", "o32"):
+        a, b = out[side], out["o64"]
+        r = {"feat%d" % i: rel(x_, y_) for i, (x_, y_) in enumerate(zip(a["feats"], b["feats"]))}
+        r.update(logits1=rel(a["logits"][0], b["logits"][0]), logits2=rel(a["logits"][1], b["logits"][1]),
+                 dlogits1=rel(a["dlogits"][0], b["dlogits"][0]), dlogits2=rel(a["dlogits"][1], b["dlogits"][1]), dx=rel(a["dx"], b["dx"]))
+        # the same backward arithmetic from EXACT dlogits would need another pass; the ratio dx / dlogits shows what the backward adds
+        res[side] = r
+    return res
+
+
 def main():
     B, lbs, H, W = 8, 4, 64, 64
     U = B - lbs
@@ -181,7 +240,7 @@ def main():
     args = dict(labeled_bs=lbs, batch_size=B, vat_iters=K, adv_losstype="dice" if "dice" in variant else "kl", vat_sign="sign" in variant)
     state = oinit.dual_decoder_2d_state(611)
     results = []
-    for s in range(4):
+    for s in range(int(os.environ.get("CHAP_DIAG_SEEDS", "4"))):
         vol, lab = ots.synthetic_batch(1441 + s, lbs, U, H, W)
         box = (9 + s, 4 + 2 * s)
         inj = inject_2d(U, lbs // 2 + U // 2, H, W, K, seed=50 * s)
@@ -204,6 +263,8 @@ def main():
         res["top_error_tensors_hip_o64"] = [{"key": k, "share_of_sq_error": e / max(sum(x for x, _ in err), 1e-300), "rel_to_total_norm": (e / den) ** 0.5} for e, k in err]
         err32 = sorted(((float(((g32[k] - g64[k]) ** 2).sum()), k) for k in keys), reverse=True)[:5]
         res["top_error_tensors_o32_o64"] = [{"key": k, "rel_to_total_norm": (e / den) ** 0.5} for e, k in err32]
+        if variant == "base":
+            res["v0_pass_stage_errors_vs_fp64"] = stage_errors(state, vol, inj, U)
         print(json.dumps(res))
         results.append(res)
     path = os.path.join(ROOT, "gpurun_out", "r04_seed_diagnosis_%s.json" % variant)

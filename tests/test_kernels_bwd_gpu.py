@@ -340,3 +340,47 @@ def test_wgrad_conv3d_ragged(dtype, shape, cin, cout, add2, brick, monkeypatch):
     tol = 1e-4 if dtype == torch.float32 else 2e-2
     assert relerr(dw - 0.25, w.grad) < tol
     assert relerr(db, gy.sum((0, 2, 3, 4))) < tol
+
+
+@pytest.mark.parametrize("mr", [2, 1])
+@pytest.mark.parametrize("cins,cout,hw,keep", [([16], 16, (40, 52), True), ([16, 16], 16, (37, 50), False), ([32], 32, (24, 40), False), ([32, 32], 32, (19, 33), True),
+                                               ([16], 4, (33, 47), False)])
+def test_wgrad_wave_private_2d(cins, cout, hw, keep, mr, monkeypatch):
+    """The wave-private weight-gradient kernel of the 2D full-resolution layers (csrc/wgrad_wp.h; bf16, round 4), forced onto small RAGGED grids
+    (H not a multiple of the 4 / 8 tile rows, W not a multiple of 16) through the library's lab knobs: one and two concatenated lazy A sources
+    (BatchNorm affine + LeakyReLU, element keep mask), 16- and 32-wide B tiles, a padded head (kn_valid), bias gradient, accumulation into existing
+    dW -- against PyTorch's conv2d weight gradient, and against the block-tile kernel (CHAP_WGRAD_WP=0) to fp32 rounding."""
+    monkeypatch.setenv("CHAP_WGRAD_WP_MR", str(mr))
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(31)
+    N, (H, W) = 3, hw
+    cin = sum(cins)
+    xs = [rq(torch.randn(N, c, H, W, generator=g), dtype) for c in cins]
+    aff = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2) for c in cins]
+    km = (torch.rand(N, cins[0], H, W, generator=g) > 0.3) if keep else None
+    acts = []
+    for i, (x, (sc, sh)) in enumerate(zip(xs, aff)):
+        acts.append(lazy_ref(x, sc, sh, 0.01, km if i == 0 else None, 1.25 if (i == 0 and keep) else 1.0))
+    a = rq(torch.cat(acts, 1), dtype)
+    cb = max(cout, 16)                                   # the head's gradient arrives padded to 16 channels
+    gy = rq(torch.randn(N, cb, H, W, generator=g), dtype)
+    if cb != cout:
+        gy[:, cout:] = 0
+    w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+    F.conv2d(a, w, None, padding=1).backward(gy[:, :cout].contiguous())
+    srcs = []
+    for i, (x, (sc, sh)) in enumerate(zip(xs, aff)):
+        kw = dict(keep=km.permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(torch.uint8).to(DEV), keep_scale=1.25) if (i == 0 and keep) else {}
+        srcs.append(ops.Lazy(cl(x, dtype), sc.to(DEV), sh.to(DEV), True, 0.01, **kw))
+    outs = {}
+    for wp in ("1", "0"):
+        monkeypatch.setenv("CHAP_WGRAD_WP", wp)
+        dw = torch.full((cout, cin, 3, 3), 0.5, device=DEV)
+        db = torch.zeros(cout, device=DEV)
+        ops.wgrad(srcs, ops.Lazy(cl(gy, dtype)), dw, (1, 9, cin * 9), grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2, db=db,
+                  kn_valid=cout if cb != cout else 0)
+        torch.cuda.synchronize()
+        outs[wp] = (dw.cpu() - 0.5, db.cpu())
+    assert relerr(outs["1"][0], w.grad) < 2e-2 and relerr(outs["1"][1], gy[:, :cout].sum((0, 2, 3))) < 2e-2
+    assert relerr(outs["1"][0], outs["0"][0]) < 2e-5 and relerr(outs["1"][1], outs["0"][1]) < 2e-5      # same products, another summation order
+    assert float(outs["1"][0].abs().max()) > 0

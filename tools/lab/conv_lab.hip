@@ -2,6 +2,7 @@
 //   1 skip MFMA (LDS fragment reads kept alive)   2 skip the whole tap loop
 //   4 force the plain (no transform) commit path  8 skip global stores   16 skip halo global loads
 #include "conv_kernel.h"
+#include "conv_kpar.h"
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -76,6 +77,57 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
     hipFree(x); hipFree(y); hipFree(wp); hipFree(sc); hipFree(sh); hipFree(st);
 }
 
+// conv_kpar_kernel (K-chunks side by side) on a 2D deep layer, with its per-wave phase stamps under -DCHAP_CONV_TRACE
+template <int KC, int NT, int CPAR>
+static void run_kpar(const char* name, int N, int H, int W, int Cin, int Cout, int bpc_max = 2) {
+    typedef uint16_t T;
+    typedef conv_geom<3, 1, false, 2> G;
+    constexpr int GPT = KC / 8, NP = G::NTAPS * GPT, STEPS = (NP + 3) / 4;
+    const int nchunks = Cin / KC, ntile16 = (Cout + 15) / 16;
+    size_t nin = (size_t)N * H * W * Cin, nout = (size_t)N * H * W * Cout;
+    T *x, *y, *wp; float *sc, *sh, *st;
+    hipMalloc(&x, nin * 2); hipMalloc(&y, nout * 2);
+    size_t wbytes_all = (size_t)nchunks * STEPS * ntile16 * 64 * 8 * 2;
+    hipMalloc(&wp, wbytes_all); hipMalloc(&sc, Cin * 4); hipMalloc(&sh, Cin * 4); hipMalloc(&st, (CHAP_STATS_HDR + (size_t)CHAP_STATS_MAX_SLOTS * 2 * Cout) * 4);
+    std::vector<T> hx(nin); for (size_t i = 0; i < nin; ++i) hx[i] = 0x3c00 + (rand() & 0x3ff);
+    hipMemcpy(x, hx.data(), nin * 2, hipMemcpyHostToDevice);
+    std::vector<T> hw(wbytes_all / 2); for (auto& v : hw) v = 0x3800 + (rand() & 0xff);
+    hipMemcpy(wp, hw.data(), wbytes_all, hipMemcpyHostToDevice);
+    std::vector<float> hs(Cin, 1.01f); hipMemcpy(sc, hs.data(), Cin * 4, hipMemcpyHostToDevice); hipMemcpy(sh, hs.data(), Cin * 4, hipMemcpyHostToDevice);
+    chap_conv_params P = {};
+    P.src[0].ptr = x; P.src[0].C = Cin; P.src[0].ld = Cin; P.src[0].slope = 0.01f; P.src[0].keep_scale = 1.f;
+    P.src[0].scale = sc; P.src[0].shift = sh; P.src[0].act = 1;
+    P.nsrc = 1; P.N = N; P.D = 1; P.H = H; P.W = W; P.ID = 1; P.IH = H; P.IW = W; P.ksize = 3; P.stride = 1; P.dims = 2;
+    P.wpacked = wp; P.out = y; P.Cout = Cout; P.out_ld = Cout; P.stats = st; P.stats_shift = nullptr; P.dtype = CHAP_BF16;
+    auto kern = chap_grouped<chap_conv_params, conv_kpar_kernel<T, false, KC, NT, CPAR, true>, 256, 2>;
+    chap_group<chap_conv_params> PG; for (int i = 0; i < CHAP_MAX_GROUP; ++i) PG.p[i] = P;
+    const size_t lds = conv_kpar_lds_bytes<T, false, KC, CPAR>(NT);
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int occ = 0; hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)kern, 256, lds);
+    long ntiles = (long)N * ((H + G::TH - 1) / G::TH) * ((W + 15) / 16);
+    int gy = (ntile16 + NT - 1) / NT;
+    long gx = ntiles;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, 0, PG);
+    hipEventRecord(e0);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), lds, 0, PG);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("kpar %-28s occ=%d grid=%5ldx%d lds=%6zu : %8.1f us per launch (back to back)\n", name, occ, gx, gy, lds, ms * 1e3 / 20);
+#ifdef CHAP_CONV_TRACE
+    unsigned long long h[4][4][16];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(chap_trace_k), sizeof(h));
+    const char* ph[10] = {"setup", "issue", "bar0", "commit", "bar1", "taps", "bar2", "red", "store", "stats"};
+    for (int b = 0; b < 4; ++b) for (int w = 0; w < 4; ++w) {
+        unsigned long long* r = h[b][w];
+        printf("  block %3d wave %d start %+6.2f us:", b * 97, w, ((double)r[0] - (double)h[0][0][0]) / 100.);
+        for (int k = 0; k < 10; ++k) printf(" %s %.2f", ph[k], ((double)r[k + 1] - (double)r[k]) / 100.);
+        printf(" | total %.2f\n", ((double)r[10] - (double)r[0]) / 100.);
+    }
+#endif
+    hipFree(x); hipFree(y); hipFree(wp); hipFree(sc); hipFree(sh); hipFree(st);
+}
+
 template <int KC, bool D3, bool ZW, int MR> static void sweep_nt(const char* tag, int N, int D, int H, int W, int C) {
     char nm[64];
     snprintf(nm, 64, "%s MR%d NT4", tag, MR); run<3, KC, 4, MR, false, D3, ZW>(nm, N, H, W, C, C, true, true, D);
@@ -130,6 +182,13 @@ int main(int argc, char** argv) {
             snprintf(t, 32, "3D 128@10x14x14 N%d", N); sweep_nt<32, true, false, 1>(t, N, 10, 14, 14, 128); sweep_nt<32, true, true, 4>(t, N, 10, 14, 14, 128);
             snprintf(t, 32, "3D 256@5x7x7 N%d", N);    sweep_nt<32, true, false, 1>(t, N, 5, 7, 7, 256); sweep_nt<32, true, true, 4>(t, N, 5, 7, 7, 256);
         }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'p') {       // 2D deep layers on the K-parallel kernel (conv_kpar.h), phase stamps per wave
+        run_kpar<32, 2, 4>("128->128@32 N12 kpar NT2 C4", 12, 32, 32, 128, 128);
+        run_kpar<32, 2, 4>("256->256@16 N12 kpar NT2 C4", 12, 16, 16, 256, 256);
+        run_kpar<32, 2, 2>("64->64@64 N12 kpar NT2 C2", 12, 64, 64, 64, 64);
+        run_kpar<32, 2, 4>("128->128@32 N24 kpar NT2 C4", 24, 32, 32, 128, 128);
         return 0;
     }
     if (argc > 1 && argv[1][0] == 'd') {       // 2D deep layers with the library's blocking (KC32 NT2 MR2, staged weights)

@@ -2,9 +2,10 @@
 
 A rocprofv3 kernel trace all but serialises the graph (10.06 ms per 2D step against 6.8 ms untraced), so it shows kernels alone, not the schedule.
 Here every launch behind the library's trampolines (csrc/launch.h; lab build with -DCHAP_TIMELINE: `make -C chap_amd/csrc -f Makefile.lab`) stamps
-the 100 MHz s_memrealtime counter into its own slot -- block (0, 0, 0) at its entry, every block (atomicMax) at its exit.  The slot pointer is baked
-into the captured graph node, so after a replay the buffer holds the start / end of every kernel of THAT replay.  The directly launched kernels
-(losses, largest-CC, VAT helpers, SGD: ~5 % of the launches) carry no stamp and show as gaps on their chain.
+the 100 MHz s_memrealtime counter into its own words -- the first, middle and last block of the grid a (start, end) pair each, plain stores (a stamp
+per block slowed the step by 26-42 %, see launch.h).  The pointer is baked into the captured graph node, so after a replay the buffer holds the start /
+end of every kernel of THAT replay.  The directly launched kernels (losses, largest-CC, VAT helpers, SGD: ~5 % of the launches) are followed by a
+one-thread marker kernel whose stamp bounds their end ("<name> (end marker)" events).
 
     CHAP_LIBPATH=tools/lab/libchap_hip_lab.so python tools/timeline_untraced.py [--config 2d|3d] [--replays 6] [--out gpurun_out/r04_timeline_untraced_2d.json]
 
@@ -34,15 +35,15 @@ TICK_US = 0.01          # s_memrealtime: 100 MHz
 
 def entries(lib, lo, hi):
     lib.chap_timeline_entry.restype = C.c_int
-    lib.chap_timeline_entry.argtypes = [C.c_long, C.c_char_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.chap_timeline_entry.argtypes = [C.c_long, C.c_char_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_long)]
     out = []
     name = C.create_string_buffer(128)
     g = (C.c_uint * 3)()
-    st, fn = C.c_void_p(), C.c_void_p()
+    st, fn, first = C.c_void_p(), C.c_void_p(), C.c_long()
     for i in range(lo, hi):
-        rc = lib.chap_timeline_entry(i, name, 128, g, C.byref(st), C.byref(fn))
+        rc = lib.chap_timeline_entry(i, name, 128, g, C.byref(st), C.byref(fn), C.byref(first))
         assert rc == 0
-        out.append(dict(name=name.value.decode(), grid=[g[0], g[1], g[2]], stream=st.value or 0, fn=fn.value or 0))
+        out.append(dict(name=name.value.decode(), grid=[g[0], g[1], g[2]], stream=st.value or 0, fn=fn.value or 0, first=first.value))
     return out
 
 
@@ -58,7 +59,7 @@ def main():
     if not hasattr(lib, "chap_timeline_enable"):
         raise SystemExit("this library has no timeline stamps: build tools/lab/libchap_hip_lab.so (make -C chap_amd/csrc -f Makefile.lab) and set CHAP_LIBPATH")
     dev = torch.device("cuda")
-    nslots = 1 << 15
+    nslots = 1 << 18                    # (start, end) pairs: three per launch recorded
     buf = torch.zeros(nslots, 2, dtype=torch.int64, device=dev)
     lib.chap_timeline_enable.argtypes = [C.c_void_p, C.c_long]
     lib.chap_timeline_count.restype = C.c_long
@@ -100,18 +101,30 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     ms_stamped = e0.elapsed_time(e1) / a.replays
-    # one clean replay: zero the end words, replay, read
-    buf[lo:hi].zero_()
+    # one clean replay: zero the words, replay, read
+    p_lo = ents[0]["first"]
+    p_hi = ents[-1]["first"] + 3
+    buf[p_lo:p_hi].zero_()
     torch.cuda.synchronize()
     step.replay(vol, lab)
     torch.cuda.synchronize()
-    t = buf[lo:hi].cpu().numpy().astype(np.int64)
+    raw = buf[p_lo:p_hi].cpu().numpy().astype(np.int64)
+    t = np.zeros((len(ents), 2), dtype=np.int64)
+    life = []
+    for i, e in enumerate(ents):
+        r = raw[e["first"] - p_lo:e["first"] - p_lo + 3]                 # first / middle / last block of the grid
+        good = (r[:, 0] > 0) & (r[:, 1] >= r[:, 0])
+        if good.any():
+            t[i] = (r[good, 0].min(), r[good, 1].max())
+            life.append(float(np.median(r[good, 1] - r[good, 0])) * TICK_US)
+        else:
+            life.append(0.0)
     ok = (t[:, 0] > 0) & (t[:, 1] >= t[:, 0])
     t0 = int(t[ok, 0].min())
     ev = []
-    for e, (s, f), good in zip(ents, t, ok):
+    for e, (s, f), good, lf in zip(ents, t, ok, life):
         if good:
-            ev.append(dict(e, start_us=(int(s) - t0) * TICK_US, end_us=(int(f) - t0) * TICK_US))
+            ev.append(dict(e, start_us=(int(s) - t0) * TICK_US, end_us=(int(f) - t0) * TICK_US, median_block_life_us=round(lf, 2)))
     ev.sort(key=lambda e: e["start_us"])
     span = max(e["end_us"] for e in ev)
     streams = sorted({e["stream"] for e in ev}, key=lambda s: (s != origin, s))
@@ -158,7 +171,8 @@ def main():
                per_kernel=[dict(name=n, launches=c, total_us=round(d, 1), avg_us=round(d / c, 2)) for n, (c, d) in sorted(per.items(), key=lambda kv: -kv[1][1])[:a.top]],
                chains=chains,
                origin_chain_overlap=[dict(name=n, total_us=round(d, 1), other_kernel_us_beside=round(o, 1)) for n, (d, o) in sorted(oc.items(), key=lambda kv: -kv[1][0])[:a.top]],
-               events=[dict(name=e["name"], grid=e["grid"], stream=sname[e["stream"]], start_us=round(e["start_us"], 2), end_us=round(e["end_us"], 2)) for e in ev])
+               events=[dict(name=e["name"], grid=e["grid"], stream=sname[e["stream"]], start_us=round(e["start_us"], 2), end_us=round(e["end_us"], 2),
+                            median_block_life_us=e["median_block_life_us"]) for e in ev])
     path = a.out or os.path.join(ROOT, "gpurun_out", "r04_timeline_untraced_%s.json" % a.config)
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
