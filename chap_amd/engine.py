@@ -107,6 +107,20 @@ def drive(gen, stream):
                     f()
 
 
+def issue_interleaved(what=7):
+    """CHAP_ISSUE_INTERLEAVE (lab / A-B switch, bit mask; default 0 = one chain after the other, the order of rounds 1-3): issue the ops of concurrent
+    chains alternately -- 1: ChapStep's phase B / phase V pass by pass, 2: the early VAT pass between pass A's encoder and decoders, 4: the two
+    decoders of a pass op by op.  The issue order is the creation order of a captured graph's nodes, and the ROCm 7.2 graph executor both feeds the
+    nodes to the GPU in that order and maps them onto its hardware queues by it: round 4 measured all three together at 8.35 ms per 2D step against
+    6.53 (the streams no longer overlap: profiles/r04_timeline_untraced_2d_interleaved.json), see DESIGN.md section 5 for the single switches."""
+    import os
+    try:
+        mask = int(os.environ.get("CHAP_ISSUE_INTERLEAVE", "0"))
+    except ValueError:
+        mask = 0
+    return bool(mask & what)
+
+
 def grouping_mode():
     """CHAP_GROUP (lab / A-B switch): 0 = never group (round 2: decoders back to back where a pass cannot fork a second stream), 1 (default) =
     group the two decoders' same-shaped layers in the passes that cannot fork one.  (Round 3 also measured grouping in EVERY pass, the
@@ -140,6 +154,7 @@ class Executor:
         self._ident = {}           # C -> (ones, zeros) for InstanceNorm (no affine)
         self._sides = {}           # parent stream -> forked stream for the second decoder
         self._capture_sides = {}   # same, for use inside a graph capture (registered by the owner of the capture)
+        self.after_trunk = None    # one-shot callable run between the trunk and the decoders of the NEXT forward pass (ChapStep: issue order, see forward_steps)
         self.has_inorm = any(op.inorm for op in program.ops)
 
     # ---------------------------------------------------------------- parameters
@@ -431,6 +446,12 @@ class Executor:
         for op in prog.ops:
             if op.branch == 0:
                 yield [lambda op=op: run_op(op)]
+        # One-shot hook between the trunk and the decoders: the caller issues ANOTHER chain's work here (ChapStep: the early VAT pass on its own
+        # stream).  Only the ISSUE ORDER changes -- the order in which a captured graph's nodes are created is the order in which a replay feeds
+        # them to the GPU (~3 us per node from the host), so work that is issued in one piece in front of a critical chain delays it.
+        hook, self.after_trunk = self.after_trunk, None
+        if hook is not None:
+            hook()
         if perturb is not None:
             # channel-level perturbation (FilterDropout.perform_dropout): every decoder gets its own version of the
             # trunk's values -- a larger batch with per-(sample, channel) multipliers -- and runs on that batch
@@ -449,14 +470,25 @@ class Executor:
             for pair in zipped:
                 yield [lambda op=op: run_dec(op) for op in pair]
         elif side is not None:
+            # two streams; the ops of the two decoders are issued ALTERNATELY (aligned schedule), not one decoder after the other: both chains
+            # are fed at the host's node rate instead of the second one's ~25 nodes standing in front of the first one's (see the hook above)
             side.wait_stream(cur_stream)
-            with torch.cuda.stream(side):
+            if len(branches) == 3 and issue_interleaved(4):
+                for pair in self._zipped():
+                    for op in pair:
+                        if op.branch >= 2:
+                            with torch.cuda.stream(side):
+                                run_dec(op)
+                        else:
+                            run_dec(op)
+            else:
+                with torch.cuda.stream(side):
+                    for op in prog.ops:
+                        if op.branch >= 2:
+                            run_dec(op)
                 for op in prog.ops:
-                    if op.branch >= 2:
+                    if op.branch == 1:
                         run_dec(op)
-            for op in prog.ops:
-                if op.branch == 1:
-                    run_dec(op)
             cur_stream.wait_stream(side)
         else:
             for op in prog.ops:
@@ -654,13 +686,22 @@ class Executor:
                     yield [lambda op=op: bwd_op(op)]
         elif side is not None:
             side.wait_stream(cur_stream)
-            with torch.cuda.stream(side):
+            if nbr == 3 and issue_interleaved(4):          # the two decoders' ops issued alternately (see forward_steps)
+                for pair in reversed(self._zipped()):
+                    for op in pair:
+                        if op.branch >= 2:
+                            with torch.cuda.stream(side):
+                                bwd_op(op)
+                        else:
+                            bwd_op(op)
+            else:
+                with torch.cuda.stream(side):
+                    for op in rev:
+                        if op.branch >= 2:
+                            bwd_op(op)
                 for op in rev:
-                    if op.branch >= 2:
+                    if op.branch == 1:
                         bwd_op(op)
-            for op in rev:
-                if op.branch == 1:
-                    bwd_op(op)
             cur_stream.wait_stream(side)
             for op in rev:
                 if op.branch == 0:

@@ -123,6 +123,17 @@ class VAT2d:
         return dict(x=x, d=d, xh=xh, first=first, inject=inject)
 
     def finish(self, model, st, soft1, soft2, mask, losstype="kl", weight_dev=None, accumulate_grad=True, grad_buffer=None, weight=1.0):
+        gen = self.finish_steps(model, st, soft1, soft2, mask, losstype, weight_dev, accumulate_grad, grad_buffer, weight)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as e:
+                return e.value
+
+    def finish_steps(self, model, st, soft1, soft2, mask, losstype="kl", weight_dev=None, accumulate_grad=True, grad_buffer=None, weight=1.0):
+        """finish() as a generator that yields between its passes -- [power iteration k: distance gradient, backward to the input, normalise] ...,
+        [final forward + distance], [final backward] -- so that the caller can ISSUE another chain's passes in between (ChapStep._iteration: the order
+        in which the nodes of a captured graph were created is the order in which a replay feeds them to the GPU, see there).  Returns the loss."""
         if losstype not in ops.DIST_MODES:
             raise ValueError("chap_amd VAT2d: adv_losstype=%r (--adv_losstype {kl,dice}, train_ours_2D.py:515)" % (losstype,))
         x, d, xh, inject = st["x"], st["d"], st["xh"], st["inject"]
@@ -140,6 +151,7 @@ class VAT2d:
             dx = model.backward_saved(l1, [g1, g2], need_wgrad=False, need_dx=True)
             model.release_saved(l1)
             ops.l2_normalize(dx, d)
+            yield
         xa = torch.empty_like(x)
         m = None if mask is None else mask.reshape(x.shape)
         alpha = self.epi / math.sqrt(x[0].numel()) if self.sign else self.epi
@@ -149,6 +161,7 @@ class VAT2d:
             l1, l2 = model(xa, update_stats=False, drop_masks=inject.get("drop_VF"), grad_buffer=grad_buffer)
             g1, g2 = torch.empty_like(l1), torch.empty_like(l2)
             ops.kl_fwd_bwd((l1, l2), (soft1, soft2), loss, (g1, g2), gscale=weight, gscale_dev=weight_dev, mode=losstype)
+            yield
             torch.autograd.backward([l1, l2], [g1, g2])
         else:
             with torch.no_grad():
@@ -354,12 +367,36 @@ class ChapStep:
         with self._decoder_fork(main):
             ctx = self._phase_a(volume_batch, label_batch, inject)
             if self.concurrent and self.args["adv_noise"]:
+                # Phase B (side stream) and phase V (this stream, the iteration's critical chain) are ISSUED pass by pass in alternation --
+                # V's power iteration, B's forward, V's final forward, B's backward, V's final backward.  The issue order is the order in which a
+                # captured graph's nodes are created, and a replay feeds the nodes to the GPU in that order at ~3 us per node from the host: with
+                # "all of phase B, then all of phase V" (rounds 1-3) the ~350 nodes of phase B were queued in front of phase V's first kernel, and
+                # the critical chain stood still for ~380 us after the fork (untraced timeline, profiles/r04_timeline_untraced_2d_before.json:
+                # diff_mask ends at 1410 us, the distance kernel behind it at 1788 us with nothing but phase B's first kernels in between).
                 self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    losses = self._phase_b(ctx)
-                    if self.grad_sync is not None and update and not torch.cuda.is_current_stream_capturing():
-                        self.grad_sync.start_first()        # bucket 0 is final: its all-reduce runs beside the VAT chain
-                vat_loss = self._phase_v(ctx)
+                gen_v, gen_b = self._phase_v_steps(ctx), self._phase_b_steps(ctx)
+                losses = vat_loss = None
+                done_v = done_b = False
+                from .engine import issue_interleaved
+                if not issue_interleaved(1):                # (default: all of phase B first, the order of rounds 1-3)
+                    with torch.cuda.stream(self._side):
+                        losses, done_b = self._drain(gen_b), True
+                        if self.grad_sync is not None and update and not torch.cuda.is_current_stream_capturing():
+                            self.grad_sync.start_first()
+                while not (done_v and done_b):
+                    if not done_v:
+                        try:
+                            next(gen_v)
+                        except StopIteration as e:
+                            vat_loss, done_v = e.value, True
+                    if not done_b:
+                        with torch.cuda.stream(self._side):
+                            try:
+                                next(gen_b)
+                            except StopIteration as e:
+                                losses, done_b = e.value, True
+                                if self.grad_sync is not None and update and not torch.cuda.is_current_stream_capturing():
+                                    self.grad_sync.start_first()        # bucket 0 is final: its all-reduce runs beside the VAT chain
                 main.wait_stream(self._side)
             else:
                 losses = self._phase_b(ctx)
@@ -404,14 +441,27 @@ class ChapStep:
         model.prepare_weights()                  # before the streams fork: every pass of the iteration reads the same packed copies
         if a["adv_noise"]:
             if pre is not None:
+                # The early pass runs on its own stream beside pass A; it is ISSUED between pass A's encoder and its decoders (Executor.after_trunk):
+                # issued in one piece in front of pass A (rounds 2-3) its ~65 nodes were queued before pass A's first kernel in every replay of the
+                # captured graph and the iteration's critical chain started ~380 us late (profiles/r04_timeline_untraced_2d_before.json).
                 pre.wait_stream(main)
-                with torch.cuda.stream(pre):
-                    ctx["vat_state"] = self.adv_loss.begin(model, volume_batch, B - lbs, inject)
+
+                def issue_early_pass():
+                    with torch.enable_grad(), torch.cuda.stream(pre):
+                        ctx["vat_state"] = self.adv_loss.begin(model, volume_batch, B - lbs, inject)
+                from .engine import issue_interleaved
+                if issue_interleaved(2):
+                    model._exec.after_trunk = issue_early_pass
+                else:
+                    issue_early_pass()
             else:
                 ctx["vat_state"] = self.adv_loss.begin(model, volume_batch, B - lbs, inject)
         # ---- pass A: pseudo labels from both decoders (no grad), train_ours_2D.py:314-330
         with torch.no_grad():
-            pre_ab1, pre_ab2 = model(ctx["uimg_ab"], drop_masks=inject.get("drop_A"))
+            try:
+                pre_ab1, pre_ab2 = model(ctx["uimg_ab"], drop_masks=inject.get("drop_A"))
+            finally:
+                model._exec.after_trunk = None
             soft1, soft2, pseudo1, pseudo2, knowledge = ops.pseudo_block(pre_ab1, pre_ab2)
         if pre is not None:
             main.wait_stream(pre)
@@ -422,10 +472,24 @@ class ChapStep:
             ctx["diff_mask"] = ops.diff_mask(pseudo1, pseudo2, knowledge, 4, a["topk1"])
         return ctx
 
+    @staticmethod
+    def _drain(gen):
+        while True:
+            try:
+                next(gen)
+            except StopIteration as e:
+                return e.value
+
     def _phase_b(self, ctx):
+        return self._drain(self._phase_b_steps(ctx))
+
+    def _phase_v(self, ctx):
+        return self._drain(self._phase_v_steps(ctx))
+
+    def _phase_b_steps(self, ctx):
         """Largest-CC filter, loss mask and BCP mixing (:326-338) feed pass B only: they run at the head of this branch, off
         the critical path (the VAT branch needs the soft / arg-max outputs, not these); then pass B and the four mix_loss
-        terms (:339-351), backward into gradient bucket 0."""
+        terms (:339-351), backward into gradient bucket 0.  A generator: yields between its forward and its backward part (see _iteration)."""
         a, model, inject = self.args, self.model, ctx["inject"]
         nc = a["num_classes"]
         lsub, usub, volume_batch = ctx["lsub"], ctx["usub"], ctx["volume_batch"]
@@ -467,6 +531,7 @@ class ChapStep:
             else:
                 ops.mix_loss_bwd(lg, img_l, patch_l, loss_mask, iw, pw, acc, dl)
             losses.append(loss3)
+        yield
         if not split:
             torch.autograd.backward([out_mix1, out_mix2], [d1, d2])
             return losses
@@ -485,12 +550,12 @@ class ChapStep:
         ops.perturb(b0, g_u, b0, 1.0)
         return losses
 
-    def _phase_v(self, ctx):
+    def _phase_v_steps(self, ctx):
         a = self.args
         if not a["adv_noise"]:
             return torch.zeros(1, dtype=torch.float32, device=ctx["volume_batch"].device)
-        return self.adv_loss.finish(self.model, ctx["vat_state"], ctx["outputs_soft1"], ctx["outputs_soft2"], ctx["diff_mask"], a["adv_losstype"],
-                                    weight_dev=self.cw_dev, grad_buffer=self.grad2)
+        return (yield from self.adv_loss.finish_steps(self.model, ctx["vat_state"], ctx["outputs_soft1"], ctx["outputs_soft2"], ctx["diff_mask"], a["adv_losstype"],
+                                                      weight_dev=self.cw_dev, grad_buffer=self.grad2))
 
     def _fp_branch(self, uimg_ab, pseudo1, pseudo2, inject, capturing):
         """"2) fp" of the loop (train_ours_2D.py:359-365, default off): both decoders on the channel-perturbed features

@@ -23,7 +23,7 @@ def run(cfg, mode):
     if mode == "noconc": a["concurrent"] = False
     step = ChapStep(m, a)
     if mode == "nob":
-        step._phase_b = lambda ctx: []
+        step._phase_b_steps = lambda ctx: iter(())          # (a generator that ends at once: phase B issues nothing; losses = None)
     if mode == "nofork":
         import contextlib
         step._decoder_fork = lambda origin: contextlib.nullcontext()

@@ -3,6 +3,7 @@
 //   4 force the plain (no transform) commit path  8 skip global stores   16 skip halo global loads
 #include "conv_kernel.h"
 #include "conv_kpar.h"
+#include "conv_kpar2d.h"
 #include <vector>
 #include <cstdio>
 #include <cstdlib>
@@ -78,7 +79,7 @@ static void run(const char* name, int N, int H, int W, int Cin, int Cout, bool p
 }
 
 // conv_kpar_kernel (K-chunks side by side) on a 2D deep layer, with its per-wave phase stamps under -DCHAP_CONV_TRACE
-template <int KC, int NT, int CPAR>
+template <int KC, int NT, int CPAR, bool NEW2D = false>
 static void run_kpar(const char* name, int N, int H, int W, int Cin, int Cout, int bpc_max = 2) {
     typedef uint16_t T;
     typedef conv_geom<3, 1, false, 2> G;
@@ -99,7 +100,11 @@ static void run_kpar(const char* name, int N, int H, int W, int Cin, int Cout, i
     P.src[0].scale = sc; P.src[0].shift = sh; P.src[0].act = 1;
     P.nsrc = 1; P.N = N; P.D = 1; P.H = H; P.W = W; P.ID = 1; P.IH = H; P.IW = W; P.ksize = 3; P.stride = 1; P.dims = 2;
     P.wpacked = wp; P.out = y; P.Cout = Cout; P.out_ld = Cout; P.stats = st; P.stats_shift = nullptr; P.dtype = CHAP_BF16;
-    auto kern = chap_grouped<chap_conv_params, conv_kpar_kernel<T, false, KC, NT, CPAR, true>, 256, 2>;
+    void (*kern)(const chap_group<chap_conv_params>) = nullptr;
+    if constexpr (NEW2D) {
+        if (Cin == 32 * CPAR) kern = chap_grouped<chap_conv_params, conv_kpar2d_kernel<NT, CPAR, true, false, true>, 256, 2>;
+        else kern = chap_grouped<chap_conv_params, conv_kpar2d_kernel<NT, CPAR, true, false, false>, 256, 2>;
+    } else kern = chap_grouped<chap_conv_params, conv_kpar_kernel<T, false, KC, NT, CPAR, true>, 256, 2>;
     chap_group<chap_conv_params> PG; for (int i = 0; i < CHAP_MAX_GROUP; ++i) PG.p[i] = P;
     const size_t lds = conv_kpar_lds_bytes<T, false, KC, CPAR>(NT);
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -189,6 +194,12 @@ int main(int argc, char** argv) {
         run_kpar<32, 2, 4>("256->256@16 N12 kpar NT2 C4", 12, 16, 16, 256, 256);
         run_kpar<32, 2, 2>("64->64@64 N12 kpar NT2 C2", 12, 64, 64, 64, 64);
         run_kpar<32, 2, 4>("128->128@32 N24 kpar NT2 C4", 24, 32, 32, 128, 128);
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 'q') {       // the round-4 form of the 2D K-parallel kernel (conv_kpar2d.h), phase stamps per wave
+        run_kpar<32, 2, 4, true>("128->128@32 N12 kpar2d C4", 12, 32, 32, 128, 128);
+        run_kpar<32, 2, 4, true>("256->256@16 N12 kpar2d C4 (2 rounds)", 12, 16, 16, 256, 256);
+        run_kpar<32, 2, 2, true>("64->64@64 N12 kpar2d C2", 12, 64, 64, 64, 64);
         return 0;
     }
     if (argc > 1 && argv[1][0] == 'd') {       // 2D deep layers with the library's blocking (KC32 NT2 MR2, staged weights)

@@ -30,6 +30,11 @@ def conv_case(N, H, cin, cout, dtype, stats, prologue, ks=3):
 
 if __name__ == "__main__":
     bf = torch.bfloat16
+    import sys as _sys
+    if len(_sys.argv) > 1 and _sys.argv[1] == "deep":        # the deep 2D layers (CHAP_CONV_KPAR=0 / 1: conv_fwd_kernel / conv_kpar2d_kernel)
+        for (H, ci, co) in ((64, 64, 64), (64, 64, 128), (32, 128, 128), (32, 128, 256), (16, 256, 256), (32, 256, 128), (64, 128, 64)):
+            conv_case(12, H, ci, co, bf, 1, 1)
+        raise SystemExit(0)
     for stats in (0, 1):
         for pro in (0, 1):
             conv_case(12, 256, 16, 16, bf, stats, pro)
