@@ -229,7 +229,7 @@ def top_kernel_roofline(dtype, N, cfg, sp=None):
                                                                       "x".join(map(str, (D, H, W) if dims == 3 else (H, W))), N),
             "bound": "mfma", "avg_launch_us": round(us, 2), "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
             "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": 2.0 * N * D * H * W * C * esz,
-            "profile": top_instance_from_profile(cfg)}
+            "profile": top_instance_from_profile(cfg) if esz == 2 else None}      # (the committed kernel statistics are bf16 runs)
 
 
 def dominant_kernel_roofline_3d(dtype, N, sp):

@@ -31,7 +31,7 @@ class ConvParams(C.Structure):
                 ("wpacked", _vp), ("bias", _vp), ("out", _vp),
                 ("Cout", _i32), ("out_ld", _i32), ("out_coff", _i32), ("out_mode", _i32), ("out_Cn", _i32),
                 ("out_planar", _i32), ("out_f32", _i32),
-                ("stats", _vp), ("stats_shift", _vp), ("dtype", _i32)]
+                ("stats", _vp), ("stats_shift", _vp), ("dtype", _i32), ("out2_from", _i32), ("out2", _vp)]
 
 
 class PackParams(C.Structure):

@@ -93,6 +93,8 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     if (p->dims == 3 && (p->src[0].keep || (p->nsrc > 1 && p->src[1].keep))) { chap_set_error("chap_conv_fwd: element keep masks are built for 2D only (3D: channel multipliers)"); return CHAP_EUNSUPPORTED; }
     if (p->out_mode == 1) CHAP_CHECK_ARG(p->out_Cn > 0 && p->out_Cn % 16 == 0 && p->Cout % p->out_Cn == 0, "chap_conv_fwd: depth-to-space needs Cn%%16==0");
     if (!p->out_planar) CHAP_CHECK_ARG(p->out_ld % 4 == 0 && p->out_coff % 4 == 0, "chap_conv_fwd: out_ld/out_coff must be multiples of 4");
+    if (p->out2) CHAP_CHECK_ARG(p->out_mode == 0 && !p->out_planar && !p->out_f32 && (p->Cout & 3) == 0 && p->out2_from > 0 && p->out2_from % 16 == 0 && p->out2_from < p->Cout &&
+                                p->ksize == 3 && p->stride == 1, "chap_conv_fwd: out2 needs a channel-last k3 s1 output, out2_from %% 16 == 0 inside (0, Cout)");
     const int Ck = p->combine == 0 ? p->src[0].C + (p->nsrc > 1 ? p->src[1].C : 0) : p->src[0].C;
     const int taps = p->ksize * p->ksize * (p->dims == 3 ? p->ksize : 1);
     conv_blocking b = blocking_for(Ck, taps, p->Cout, p->dtype);
@@ -155,7 +157,7 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
         return chap_launch<chap_conv_params, conv_head1x1_kernel<bf16_t>, 256>(dim3(chap_blocks(total, 4096)), dim3(256), 0, (hipStream_t)stream, *p, "chap_conv_fwd(head)");
     }
     // ---- the deep, small 3x3(x3) layers: K-chunks side by side (conv_kpar.h) instead of one after the other
-    if (p->dtype == CHAP_BF16 && (geom == 1 || geom == 2) && p->out_mode == 0 && !p->out_planar && (p->Cout & 3) == 0 &&
+    if (p->dtype == CHAP_BF16 && (geom == 1 || geom == 2) && p->out_mode == 0 && !p->out_planar && (p->Cout & 3) == 0 && !p->out2 &&
         (p->nsrc == 1 || (p->combine == 0 && p->src[0].C % b.KC == 0)) && !(d3 && (p->src[0].keep || (p->nsrc > 1 && p->src[1].keep)))) {
         // Measured per layer shape (tools/shape_table.py with CHAP_CONV_KPAR = 0 / 1, gpurun_out/kpar*.log), kernel alone: it wins while the
         // launch is about one wave of blocks -- 3D 256->256 at 7x7x5 23.3 -> 14.4 us, 128->128 at 14x14x10 20.5 -> 17.0, 256->128 39.1 -> 29.6;

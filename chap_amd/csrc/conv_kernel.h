@@ -600,7 +600,7 @@ __device__ __forceinline__ void conv_fwd_kernel(const chap_conv_params& P) {
                 const int sx = sub & 1, sy = (sub >> 1) & 1, sz = (sub >> 2) & 1;
                 ooff[t] = (((sz * OH) + sy) * OW + 2 * px + sx) * P.out_ld + P.out_coff + oc;
             } else {
-                ooff[t] = px * P.out_ld + P.out_coff + nl;
+                ooff[t] = px * P.out_ld + P.out_coff + ((P.out2 && nl >= P.out2_from) ? nl - P.out2_from : nl);      // (out2: the upper channel tiles land in a second dense tensor)
             }
         }
         orow = P.out_planar ? P.W : (P.out_mode == 1 ? 2 * OW * P.out_ld : P.W * P.out_ld);
@@ -731,11 +731,13 @@ __device__ __forceinline__ void conv_fwd_kernel(const chap_conv_params& P) {
                 // tiles with a full channel group (wave-uniform test; nearly all of them) skip the per-lane validity:
                 // no selects in the statistics, no exec masking around the stores.
                 char* ob = (char*)P.out + o0 * (P.out_f32 ? 4 : (long)sizeof(T));
+                char* ob2 = P.out2 ? (char*)P.out2 + o0 * (long)sizeof(T) : ob;
                 const bool full = (x0 + G::TW <= P.W) && (y0 + G::TH <= P.H) && (!ZW || z0 + G::TD <= P.D) && ((nt0 + NT) * 16 <= P.Cout);
                 auto emit = [&](auto FULL) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const bool cok = (nt0 + t) * 16 + 4 * g < P.Cout;
+                        char* obt = (P.out2 && (nt0 + t) * 16 >= P.out2_from) ? ob2 : ob;      // wave-uniform
 #pragma unroll
                         for (int m = 0; m < MR; ++m) {
                             const int row = ZW ? m : wave * MR + m;
@@ -756,7 +758,7 @@ __device__ __forceinline__ void conv_fwd_kernel(const chap_conv_params& P) {
                             if (CHAP_ABLATE & 8) { asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3])); continue; }
                             const unsigned oi = (unsigned)(row * orow + zw_off + ooff[t]);
                             if (valid) {
-                                if (P.out_f32) st4((float*)(ob + oi * 4u), v); else st4((T*)(ob + oi * (unsigned)sizeof(T)), v);
+                                if (P.out_f32) st4((float*)(ob + oi * 4u), v); else st4((T*)(obt + oi * (unsigned)sizeof(T)), v);
                             }
                         }
                     }

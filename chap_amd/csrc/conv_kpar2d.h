@@ -135,6 +135,7 @@ __device__ __forceinline__ void conv_kpar2d_kernel(const chap_conv_params& P) { 
         int n, z0, y0, x0;
         tile_coords<G::TH, G::TW, 1>(tile, tiles_x, tiles_y, P.D, n, z0, y0, x0);
         f32x4 acc[RW][NT];
+        float bj[NT][4], cj[NT][4];                             // bias / statistics shift: requested behind the last round's staging, they land during its tap loop
         if constexpr (!SINGLE) {
 #pragma unroll
             for (int m = 0; m < RW; ++m)
@@ -181,6 +182,20 @@ __device__ __forceinline__ void conv_kpar2d_kernel(const chap_conv_params& P) { 
             __syncthreads();
             CHAP_KSTAMP(5);
             __builtin_amdgcn_sched_barrier(0);                  // (keep the accumulators' zeroing and the tap loop's loads behind the staging: its registers are all taken)
+            if (r == nrounds - 1) {
+                const float* bsrc = P.bias ? P.bias : (const float*)P.wpacked;      // any valid address when there is no bias: no branch around the loads
+                const bool has_shift = do_stats && P.stats_shift != nullptr;
+                const float* csrc = has_shift ? P.stats_shift : (const float*)P.wpacked;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int nl = (nt0 + t) * 16 + 4 * g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bj[t][j] = bsrc[(P.bias && nl + j < P.Cout) ? nl + j : 0];
+                        cj[t][j] = csrc[(has_shift && nl + j < P.Cout) ? nl + j : 0];
+                    }
+                }
+            }
             if constexpr (SINGLE) {
                 load_wcol(2);
 #pragma unroll
@@ -206,23 +221,6 @@ __device__ __forceinline__ void conv_kpar2d_kernel(const chap_conv_params& P) { 
             }
         }
         // ---- the CPAR partial sums of every row meet in LDS; wave f finishes rows [f*FR, f*FR + FR)
-        // bias and statistics shift: requested here (not live across the staging and the tap loop: those phases have no register to spare), they
-        // land while the partial sums cross the two barriers below
-        float bj[NT][4], cj[NT][4];
-        {
-            const float* bsrc = P.bias ? P.bias : (const float*)P.wpacked;      // any valid address when there is no bias: no branch around the loads
-            const bool has_shift = do_stats && P.stats_shift != nullptr;
-            const float* csrc = has_shift ? P.stats_shift : (const float*)P.wpacked;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int nl = (nt0 + t) * 16 + 4 * g;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    bj[t][j] = bsrc[(P.bias && nl + j < P.Cout) ? nl + j : 0];
-                    cj[t][j] = csrc[(has_shift && nl + j < P.Cout) ? nl + j : 0];
-                }
-            }
-        }
         CHAP_KSTAMP(6);
         __syncthreads();                                        // every wave is done reading the halos
         CHAP_KSTAMP(7);

@@ -28,14 +28,16 @@ static int wg_make_plan(const chap_wgrad_params* p, wg_plan* q) {
         if (p->dims == 3 && p->ksize == 3 && p->stride == 1 && p->dtype == CHAP_BF16 && min_bricks > 0 && bricks >= min_bricks &&
             p->a[0].C <= 256 && (p->na < 2 || p->a[1].C <= 256) && p->b.C <= 256) { q->brick = 1; q->KC = 16; }      // (<= 256 channels per source: the brick kernels' scale/shift cache)
     }
-    // 2D 3x3 layers on large images, bf16: wave-private pipelines (wgrad_wp.h; brick == 2), 16-channel A chunks.  CHAP_WGRAD_WP (lab knob): 0 = never,
-    // N = from N tiles (8 x 16 pixels) up.
+    // 2D 3x3 layers, bf16, <= 256 channels per source: wave-private pipelines (wgrad_wp.h; brick == 2), 16-channel A chunks.  CHAP_WGRAD_WP (lab knob):
+    // 0 = never, N = from N tiles (8 x 16 pixels) up.  Default 1 = every eligible layer: the large images gain most (16->16 at 256 x 256 36.8 -> 25.2 us),
+    // the deep layers 10-18 % (128->128 at 32 x 32 29.2 -> 25.9 us, 64+64->64 at 64 x 64 41.0 -> 33.8); whole 2D iteration, three A/B pairs per setting:
+    // threshold 1024 / 256 / 64 / 1 -> 6.513 / 6.513 / 6.506 / 6.476 ms (profiles/r04_wgrad_wp_ab.log).
     {
         const char* e = getenv("CHAP_WGRAD_WP");        // (read per call: the tests force the kernel onto small ragged grids)
-        const long wp_min = e ? atol(e) : 1024;
+        const long wp_min = e ? atol(e) : 1;
         const long t8 = (long)p->N * cdiv(p->H, 8) * cdiv(p->W, 16);
         if (p->dims == 2 && p->ksize == 3 && p->stride == 1 && p->combine == 0 && p->dtype == CHAP_BF16 && wp_min > 0 && t8 >= wp_min &&
-            p->a[0].C <= 128 && p->a[0].C % 16 == 0 && (p->na < 2 || (p->a[1].C <= 128 && p->a[1].C % 16 == 0)) && p->b.C <= 128) { q->brick = 2; q->KC = 16; }
+            p->a[0].C <= 256 && p->a[0].C % 16 == 0 && (p->na < 2 || (p->a[1].C <= 256 && p->a[1].C % 16 == 0)) && p->b.C <= 256) { q->brick = 2; q->KC = 16; }
     }
     // (tried: 16 x 16 tiles for the 2D 16-channel levels -- 16->16 at 256x256 35.8 -> 32.9 us with 512 blocks, 16+16->16 unchanged: not kept)
     CHAP_CHECK_ARG(q->Ca % q->KC == 0, "chap_wgrad: Ca=%d not a multiple of %d", q->Ca, q->KC);

@@ -15,7 +15,7 @@
 #pragma once
 #include "wgrad_kernel.h"
 
-constexpr int WP_AFFC = 256;           // scale | shift halves of 128 channels per source (the layers routed here have <= 64)
+constexpr int WP_AFFC = 512;           // scale | shift halves of 256 channels per source
 
 template <int KC, int MR, int BN>
 __host__ __device__ constexpr size_t wgrad_wp_lds_bytes() {

@@ -121,6 +121,12 @@ def issue_interleaved(what=7):
     return bool(mask & what)
 
 
+def split_concat_gradient():
+    """CHAP_SPLIT_CONCAT (lab / A-B switch, default 1): the input gradient of a concat layer as two dense tensors (chap_conv_params.out2)."""
+    import os
+    return os.environ.get("CHAP_SPLIT_CONCAT", "1") != "0"
+
+
 def grouping_mode():
     """CHAP_GROUP (lab / A-B switch): 0 = never group (round 2: decoders back to back where a pass cannot fork a second stream), 1 (default) =
     group the two decoders' same-shaped layers in the passes that cannot fork one.  (Round 3 also measured grouping in EVERY pass, the
@@ -647,9 +653,20 @@ class Executor:
                     ops.wgrad(srcs, g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
                               ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid)
                 wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
-                dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
-                ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
-                scatter(op, srcs, dsrc)
+                if (len(srcs) == 2 and op.combine == 0 and op.ksize == 3 and srcs[0].C == srcs[1].C and srcs[0].C % 16 == 0 and S.tables is None
+                        and split_concat_gradient()):
+                    # the input was torch.cat((skip, up), 1) (unet.py:98): its gradient as two DENSE tensors, one per source (chap_conv_params.out2) -- the
+                    # BatchNorm backward of either source then reads whole 32-byte sectors instead of a 16-channel slice of a 32-channel row (round 3:
+                    # FETCH_SIZE 1.25 x the algorithmic bytes of act_bwd at C = 16, 256 x 256)
+                    d0 = L.hold_empty(n, sd_, sh_, sw_, srcs[0].C, dtype=dtype, device=dev)
+                    d1 = L.hold_empty_like(d0)
+                    ops.conv_fwd([g], wp, None, ctot, d0, grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims, out2=d1)
+                    for name, t in zip(op.srcs, (d0, d1)):
+                        contrib.setdefault(name, []).append((t, 0, okey[id(op)]))
+                else:
+                    dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
+                    ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_), ksize=op.ksize, stride=1, dims=dims)
+                    scatter(op, srcs, dsrc)
             elif k == "down":
                 gdd = S.dims[op.out]
                 if need_wgrad:

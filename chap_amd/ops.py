@@ -68,9 +68,9 @@ def pack_weights(w, kind, dtype, cin, cout, taps):
 
 def conv_fwd(srcs, wpacked, bias, cout, out, *, grid, in_dims, ksize, stride, dims, combine=0,
              out_ld=None, out_coff=0, out_mode=0, out_cn=0, out_planar=False, out_f32=False,
-             stats=None, stats_shift=None):
+             stats=None, stats_shift=None, out2=None):
     """stats: fp32 buffer from `stats_buffer(cout)` (per-block partial slots of the shifted moments, chap_hip.h);
-    stats_shift: fp32 [real channels] or None."""
+    stats_shift: fp32 [real channels] or None.  out2: a second output tensor taking the channels [out.shape[-1], cout) (chap_conv_params.out2)."""
     p = L.ConvParams()
     for i, s in enumerate(srcs):
         s.fill(p.src[i])
@@ -85,6 +85,9 @@ def conv_fwd(srcs, wpacked, bias, cout, out, *, grid, in_dims, ksize, stride, di
     p.out_planar, p.out_f32 = int(out_planar), int(out_f32)
     p.stats, p.stats_shift = _p(stats), _p(stats_shift)
     p.dtype = dt(srcs[0].raw)
+    if out2 is not None:
+        assert out2.shape == out.shape and out2.dtype == out.dtype and cout == 2 * out.shape[-1]
+        p.out2, p.out2_from = out2.data_ptr(), out.shape[-1]
     L.call("chap_conv_fwd", p, _stream())
 
 

@@ -122,30 +122,33 @@ class VAT2d:
                 first = model(xh, update_stats=False, drop_masks=inject.get("drop_V0"))
         return dict(x=x, d=d, xh=xh, first=first, inject=inject)
 
-    def finish(self, model, st, soft1, soft2, mask, losstype="kl", weight_dev=None, accumulate_grad=True, grad_buffer=None, weight=1.0):
-        gen = self.finish_steps(model, st, soft1, soft2, mask, losstype, weight_dev, accumulate_grad, grad_buffer, weight)
+    def finish(self, model, st, soft1, soft2, mask, losstype="kl", weight_dev=None, accumulate_grad=True, grad_buffer=None, weight=1.0, fork_ctl=None):
+        gen = self.finish_steps(model, st, soft1, soft2, mask, losstype, weight_dev, accumulate_grad, grad_buffer, weight, fork_ctl)
         while True:
             try:
                 next(gen)
             except StopIteration as e:
                 return e.value
 
-    def finish_steps(self, model, st, soft1, soft2, mask, losstype="kl", weight_dev=None, accumulate_grad=True, grad_buffer=None, weight=1.0):
+    def finish_steps(self, model, st, soft1, soft2, mask, losstype="kl", weight_dev=None, accumulate_grad=True, grad_buffer=None, weight=1.0, fork_ctl=None):
         """finish() as a generator that yields between its passes -- [power iteration k: distance gradient, backward to the input, normalise] ...,
         [final forward + distance], [final backward] -- so that the caller can ISSUE another chain's passes in between (ChapStep._iteration: the order
         in which the nodes of a captured graph were created is the order in which a replay feeds them to the GPU, see there).  Returns the loss."""
         if losstype not in ops.DIST_MODES:
             raise ValueError("chap_amd VAT2d: adv_losstype=%r (--adv_losstype {kl,dice}, train_ours_2D.py:515)" % (losstype,))
         x, d, xh, inject = st["x"], st["d"], st["xh"], st["inject"]
+        fork_ctl = fork_ctl or (lambda bit: None)      # (ChapStep: which passes of the chain may fork their second decoder under capture, CHAP_FORK_MASK)
         for it in range(self.ip):
             if it == 0:
                 l1, l2 = st["first"]
             else:
                 ops.perturb(x, d, xh, self.xi)
+                fork_ctl(4)
                 with model.frozen():
                     l1, l2 = model(xh, update_stats=False, drop_masks=inject.get("drop_V%d" % it))
             g1, g2 = torch.empty_like(l1), torch.empty_like(l2)
             ops.kl_fwd_bwd((l1, l2), (soft1, soft2), None, (g1, g2), mode=losstype)
+            fork_ctl(2)
             # d(distance)/d(x) only (the weights are frozen: no weight-gradient kernels), on the CURRENT stream whatever stream the
             # forward ran on (torch.autograd would run the node on the forward's stream)
             dx = model.backward_saved(l1, [g1, g2], need_wgrad=False, need_dx=True)
@@ -158,10 +161,12 @@ class VAT2d:
         ops.perturb(x, d, xa, alpha, mask=m, sign=self.sign)
         loss = torch.zeros(1, dtype=torch.float32, device=x.device)
         if accumulate_grad:
+            fork_ctl(4)
             l1, l2 = model(xa, update_stats=False, drop_masks=inject.get("drop_VF"), grad_buffer=grad_buffer)
             g1, g2 = torch.empty_like(l1), torch.empty_like(l2)
             ops.kl_fwd_bwd((l1, l2), (soft1, soft2), loss, (g1, g2), gscale=weight, gscale_dev=weight_dev, mode=losstype)
             yield
+            fork_ctl(8)
             torch.autograd.backward([l1, l2], [g1, g2])
         else:
             with torch.no_grad():
@@ -408,6 +413,18 @@ class ChapStep:
             self.exchange_and_update()
         return out
 
+    def _fork_ctl(self, bit):
+        """CHAP_FORK_MASK (lab / A-B switch, default 14): which passes of the capture's origin stream fork their second decoder onto a stream of its own
+        (1 pass A, 2 the power iteration's backward, 4 the VAT forward passes after the first, 8 the final backward); the others run their decoders with
+        grouped launches.  Every fork is one more chain for the graph executor to place on its few hardware queues (see engine.issue_interleaved).
+        Round 4, 12 masks on the whole iteration (profiles/r04_issue_order_ab.log): 14 -- pass A, which already shares the GPU with the early VAT pass,
+        keeps its decoders on one stream -- 6.469 ms against 6.513 for 15 (three pairs; 3D 14.79 vs 14.81), every other mask slower (0: 6.83 / 15.8)."""
+        cs = getattr(self, "_cs_active", None)
+        if cs is None:
+            return
+        mask = int(os.environ.get("CHAP_FORK_MASK", "14"))
+        self.model._exec._capture_sides = cs if (mask & bit) else {}
+
     @contextlib.contextmanager
     def _decoder_fork(self, origin):
         """Under capture: let the executor run the second decoder of the passes on `origin` on a stream forked from it (a
@@ -415,13 +432,15 @@ class ChapStep:
         capturing = self.concurrent and torch.cuda.is_current_stream_capturing()
         if capturing:
             self._d2.wait_stream(origin)
-            self.model._exec._capture_sides = {origin.cuda_stream: self._d2}
+            self._cs_active = {origin.cuda_stream: self._d2}
+            self.model._exec._capture_sides = self._cs_active
         try:
             yield
         finally:
             if capturing:
                 origin.wait_stream(self._d2)
                 self.model._exec._capture_sides = {}
+                self._cs_active = None
 
     def _phase_a(self, volume_batch, label_batch, inject):
         a, model = self.args, self.model
@@ -457,6 +476,7 @@ class ChapStep:
             else:
                 ctx["vat_state"] = self.adv_loss.begin(model, volume_batch, B - lbs, inject)
         # ---- pass A: pseudo labels from both decoders (no grad), train_ours_2D.py:314-330
+        self._fork_ctl(1)
         with torch.no_grad():
             try:
                 pre_ab1, pre_ab2 = model(ctx["uimg_ab"], drop_masks=inject.get("drop_A"))
@@ -555,7 +575,7 @@ class ChapStep:
         if not a["adv_noise"]:
             return torch.zeros(1, dtype=torch.float32, device=ctx["volume_batch"].device)
         return (yield from self.adv_loss.finish_steps(self.model, ctx["vat_state"], ctx["outputs_soft1"], ctx["outputs_soft2"], ctx["diff_mask"], a["adv_losstype"],
-                                                      weight_dev=self.cw_dev, grad_buffer=self.grad2))
+                                                      weight_dev=self.cw_dev, grad_buffer=self.grad2, fork_ctl=self._fork_ctl))
 
     def _fp_branch(self, uimg_ab, pseudo1, pseudo2, inject, capturing):
         """"2) fp" of the loop (train_ours_2D.py:359-365, default off): both decoders on the channel-perturbed features

@@ -41,7 +41,7 @@
  *   7  the round-3 experiments that lost their whole-iteration A/B are gone from the ABI: capture points (graph branches / leaves on one
  *      stream: +15-22 % step time), the "lazy gradient" chap_bgrad_t of chap_wgrad (+0.8 / +2.7 %), the deferred multi-layer slab reduction
  *      (+-0 / +1 %); measurements in DESIGN.md section 5.  chap_conv_params.out2 / out2_from (a concat layer's input gradient as two dense
- *      tensors), chap_conv_params.up (the x2 up-sampling gather fused into the conv's halo staging).
+ *      tensors).
  */
 #ifndef CHAP_HIP_H
 #define CHAP_HIP_H
@@ -118,6 +118,10 @@ typedef struct {
     float*      stats;         /* partial slots (layout above) or NULL                            */
     const float* stats_shift;  /* [real channels] or NULL: the c of the shifted moments           */
     int32_t     dtype;
+    int32_t     out2_from;     /* ABI 7, with out2: output channels [out2_from, Cout) go to out2 (channel c - out2_from), [0, out2_from) to out.  The    */
+    void*       out2;          /* input gradient of a layer whose input was torch.cat((a, b), 1) (unet.py:98) as two DENSE tensors: the consumers of a  */
+                               /* half (BatchNorm backward) read whole sectors instead of a 16-channel slice of 32-channel rows.  Same out_ld / out_coff; */
+                               /* out_mode 0, channel-last, out2_from % 16 == 0; NULL = off                                                             */
 } chap_conv_params;
 
 int chap_conv_fwd(const chap_conv_params* p, void* stream);

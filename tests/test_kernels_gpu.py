@@ -483,3 +483,24 @@ def test_group_region_contract():
         with L.group(st):
             ops.sgd_step(p, torch.ones(64, device=DEV), m, lr, 0.9, 0.0)
     assert L.group.held is None                             # the region was left
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,half,hw", [(16, 16, (37, 52)), (64, 64, (20, 24)), (32, 32, (16, 40))])
+def test_conv_two_dense_outputs(dtype, cin, half, hw):
+    """chap_conv_params.out2 (ABI 7): the input gradient of a concat layer (torch.cat((skip, up), 1), unet.py:98) written as two dense tensors, one per
+    source -- bit for bit the two channel halves of the single [.., 2 * half] output, also where one block's channel tiles straddle the split (16 + 16)."""
+    g = torch.Generator().manual_seed(41)
+    N, (H, W) = 2, hw
+    cout = 2 * half
+    x = cl(rq(torch.randn(N, cin, H, W, generator=g), dtype), dtype)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, cin, cout, 9)
+    one = torch.full((N, 1, H, W, cout), float("nan"), device=DEV, dtype=dtype)
+    ops.conv_fwd([ops.Lazy(x)], wp, None, cout, one, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2)
+    d0 = torch.full((N, 1, H, W, half), float("nan"), device=DEV, dtype=dtype)
+    d1 = torch.full((N, 1, H, W, half), float("nan"), device=DEV, dtype=dtype)
+    ops.conv_fwd([ops.Lazy(x)], wp, None, cout, d0, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2, out2=d1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(one.float()).all()
+    assert torch.equal(d0, one[..., :half].contiguous()) and torch.equal(d1, one[..., half:].contiguous())

@@ -40,3 +40,6 @@ if __name__ == "__main__":
     case("64->64 @64", N, 64, 64, [64], 64)
     case("64+64->64 @64", N, 64, 64, [64, 64], 64)
     case("128->128 @32", N, 32, 32, [128], 128)
+    case("128+128->128 @32", N, 32, 32, [128, 128], 128)
+    case("256->256 @16", N, 16, 16, [256], 256)
+    case("64->128 @64", N, 64, 64, [64], 128)
