@@ -5,6 +5,7 @@
 #include "launch.h"
 
 int chap_conv_launch_kpar_bf16(const chap_conv_params* p, int KC, int cpar, hipStream_t s);
+int chap_conv_launch_wp_bf16(const chap_conv_params* p, int KC, hipStream_t s);
 #define DECL_GEOM(dt, g) int chap_conv_launch_##dt##_g##g(const chap_conv_params* p, int KC, int NT, int MR, hipStream_t s);
 DECL_GEOM(bf16, 1) DECL_GEOM(bf16, 2) DECL_GEOM(bf16, 3) DECL_GEOM(bf16, 4) DECL_GEOM(bf16, 5)
 DECL_GEOM(f32, 1) DECL_GEOM(f32, 2) DECL_GEOM(f32, 3) DECL_GEOM(f32, 4) DECL_GEOM(f32, 5)
@@ -155,6 +156,18 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     if (p->dtype == CHAP_BF16 && geom == 3 && p->out_planar && p->Cout <= 8 && p->nsrc == 1 && Ck == 16 && p->src[0].C == 16 && !p->stats && p->out_mode == 0) {
         const long total = (long)p->N * p->D * p->H * p->W;
         return chap_launch<chap_conv_params, conv_head1x1_kernel<bf16_t>, 256>(dim3(chap_blocks(total, 4096)), dim3(256), 0, (hipStream_t)stream, *p, "chap_conv_fwd(head)");
+    }
+    // ---- the 2D full-resolution layers (all input channels in ONE chunk of 16 or 32): wave-private pipelines (conv_wp.h), bf16.  CHAP_CONV_WP (lab knob):
+    // 0 = never, N = from N tiles of 4 x 16 pixels up (default 1: every eligible layer).  Stand-alone (profiles/r04_conv_wp_ab.log): 16->32 at 256 x 256
+    // 34.1 -> 29.1 us, 32->16 32.0 -> 25.1, 32->64 at 128 x 128 20.6 -> 17.9, 16->32 at 128 x 128 14.9 -> 13.0; the 16->16 layer with BatchNorm prologue and
+    // statistics 20.8 -> 20.5 (it is VALU-bound in its staging, not short of loads in flight), 32->32 with statistics 14.7 -> 15.3.  Whole 2D iteration, three
+    // A/B pairs: 6.451 -> 6.406 ms.  Outputs are bit-identical to conv_fwd_kernel's.
+    if (p->dtype == CHAP_BF16 && geom == 1 && p->out_mode == 0 && !p->out_planar && !p->out_f32 && (p->Cout & 15) == 0 && p->Cout <= 64 && p->combine == 0 &&
+        Ck == b.KC && (p->nsrc == 1 || (b.KC == 32 && p->src[0].C == 16 && p->src[1].C == 16))) {
+        const char* ew = getenv("CHAP_CONV_WP");
+        const long wp_min = ew ? atol(ew) : 1;
+        const long t4 = (long)p->N * cdiv(p->H, 4) * cdiv(p->W, 16);
+        if (wp_min > 0 && t4 >= wp_min) return chap_conv_launch_wp_bf16(p, b.KC, (hipStream_t)stream);
     }
     // ---- the deep, small 3x3(x3) layers: K-chunks side by side (conv_kpar.h) instead of one after the other
     if (p->dtype == CHAP_BF16 && (geom == 1 || geom == 2) && p->out_mode == 0 && !p->out_planar && (p->Cout & 3) == 0 && !p->out2 &&

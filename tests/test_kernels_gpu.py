@@ -504,3 +504,48 @@ def test_conv_two_dense_outputs(dtype, cin, half, hw):
     torch.cuda.synchronize()
     assert torch.isfinite(one.float()).all()
     assert torch.equal(d0, one[..., :half].contiguous()) and torch.equal(d1, one[..., half:].contiguous())
+
+
+@pytest.mark.parametrize("cins,cout,hw,keep,split", [([16], 16, (37, 52), True, False), ([16], 32, (40, 33), False, True), ([32], 32, (24, 40), False, False),
+                                                     ([16, 16], 16, (19, 50), True, False), ([32], 64, (21, 36), False, False), ([32], 16, (9, 70), False, False)])
+def test_conv_wave_private_2d(cins, cout, hw, keep, split, monkeypatch):
+    """The wave-private convolution kernel of the 2D full-resolution layers (csrc/conv_wp.h; bf16, all input channels in one chunk of 16 or 32), forced
+    onto small RAGGED grids: lazy BatchNorm-affine + LeakyReLU sources (one, or two concatenated inside the chunk), element keep mask, bias, shifted
+    statistics, the two-tensor output of a concat layer's input gradient -- outputs BIT-IDENTICAL to conv_fwd_kernel (the same MFMA sequence per output
+    element), statistics totals equal to fp32 rounding (another dealing of pixels to slots), both against torch."""
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(53)
+    N, (H, W) = 3, hw
+    cin = sum(cins)
+    lazies, refs = [], []
+    for i, c in enumerate(cins):
+        x = rq(torch.randn(N, c, H, W, generator=g), dtype)
+        sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
+        km = (torch.rand(N, c, H, W, generator=g) > 0.3).float() if (keep and i == 0) else None
+        refs.append(rq(lazy_ref(x, sc, sh, 0.01, km, 1.25 if km is not None else 1.0), dtype))
+        lazies.append(ops.Lazy(cl(x, dtype), sc.to(DEV), sh.to(DEV), True, 0.01, keep=None if km is None else cl(km, torch.uint8), keep_scale=1.25 if km is not None else 1.0))
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(torch.cat(refs, 1), rq(w, dtype), b, padding=1)
+    wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, cin, cout, 9)
+    cshift = torch.randn(cout, generator=g)
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("CHAP_CONV_WP", mode)
+        stats = ops.stats_buffer(cout, DEV)
+        if split:
+            o0 = torch.full((N, 1, H, W, cout // 2), float("nan"), device=DEV, dtype=dtype)
+            o1 = torch.full_like(o0, float("nan"))
+            ops.conv_fwd(lazies, wp, b.to(DEV), cout, o0, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2, stats=stats, stats_shift=cshift.to(DEV), out2=o1)
+            out = torch.cat((o0, o1), -1)
+        else:
+            out = torch.full((N, 1, H, W, cout), float("nan"), device=DEV, dtype=dtype)
+            ops.conv_fwd(lazies, wp, b.to(DEV), cout, out, grid=(N, 1, H, W), in_dims=(1, H, W), ksize=3, stride=1, dims=2, stats=stats, stats_shift=cshift.to(DEV))
+        torch.cuda.synchronize()
+        got[mode] = (out.clone(), ops.stats_totals(stats, cout).float().cpu())
+    assert torch.isfinite(got["1"][0].float()).all()
+    assert torch.equal(got["1"][0], got["0"][0])
+    assert relerr(uncl(got["1"][0]), ref.unsqueeze(2)) < TOL[dtype]
+    assert relerr(got["1"][1], got["0"][1]) < 1e-4
+    rc = ref - cshift.view(1, -1, 1, 1)
+    assert relerr(got["1"][1][0], rc.sum((0, 2, 3))) < 1e-3 + TOL[dtype]

@@ -31,6 +31,10 @@ def conv_case(N, H, cin, cout, dtype, stats, prologue, ks=3):
 if __name__ == "__main__":
     bf = torch.bfloat16
     import sys as _sys
+    if len(_sys.argv) > 1 and _sys.argv[1] == "shallow":     # the full-resolution 2D layers (CHAP_CONV_WP=0 / 1: conv_fwd_kernel / conv_wp_kernel)
+        for (H, ci, co, st, pro) in ((256, 16, 16, 1, 1), (256, 16, 16, 0, 0), (256, 16, 32, 0, 0), (256, 32, 16, 1, 1), (128, 32, 32, 1, 1), (128, 32, 32, 0, 0), (128, 32, 64, 0, 0), (128, 16, 32, 1, 0)):
+            conv_case(12, H, ci, co, bf, st, pro)
+        raise SystemExit(0)
     if len(_sys.argv) > 1 and _sys.argv[1] == "deep":        # the deep 2D layers (CHAP_CONV_KPAR=0 / 1: conv_fwd_kernel / conv_kpar2d_kernel)
         for (H, ci, co) in ((64, 64, 64), (64, 64, 128), (32, 128, 128), (32, 128, 256), (16, 256, 256), (32, 256, 128), (64, 128, 64)):
             conv_case(12, H, ci, co, bf, 1, 1)
