@@ -112,8 +112,9 @@ def cpu_baseline(args, B, sp):
 
 
 def dominant_kernel_roofline(model, dtype, N, H):
-    """HIP-event timing of the dominant kernel (the 16->16 3x3 implicit-GEMM conv at full resolution,
-    `conv_fwd_kernel<.., KC=16, NT=1>`) on the stream it is launched on, on the real layer shape."""
+    """HIP-event timing of the dominant kernel (the 16->16 3x3 implicit-GEMM conv at full resolution: since round 4 the
+    wave-private `conv_wp_kernel<KC=16, NT=1>` in bf16, `conv_fwd_kernel<.., KC=16, NT=1>` in fp32 or with CHAP_CONV_WP=0) on the
+    stream it is launched on, on the real layer shape."""
     from chap_amd import _lib as L
     from chap_amd import ops
     dev = torch.device("cuda")
@@ -141,7 +142,9 @@ def dominant_kernel_roofline(model, dtype, N, H):
     esz = 2 if dtype == torch.bfloat16 else 4
     alg_bytes = 2.0 * N * H * H * 16 * esz                      # read the input once + write the output once
     ach = alg_bytes / (us * 1e-6) / 1e9
-    kname = "conv_fwd_kernel<%s,3,1,2D,KC16,NT1> 16->16 @%dx%d N=%d" % ("bf16" if esz == 2 else "f32", H, H, N)
+    wp = esz == 2 and os.environ.get("CHAP_CONV_WP", "1") != "0"          # the routing rule of csrc/conv_api.hip
+    kname = ("conv_wp_kernel<bf16,KC16,NT1> 16->16 @%dx%d N=%d" % (H, H, N) if wp else
+             "conv_fwd_kernel<%s,3,1,2D,KC16,NT1> 16->16 @%dx%d N=%d" % ("bf16" if esz == 2 else "f32", H, H, N))
     traffic = None                 # HBM bytes per launch from the committed rocprofv3 --pmc passes (same kernel, same shape)
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_dominant_kernel.json")))

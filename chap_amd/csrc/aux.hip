@@ -166,7 +166,10 @@ __global__ void diffmask_pool_kernel(const chap_diffmask_params P) {
 }
 // one block per sample: radix-select (8 bits per pass, 256-bin LDS histogram) the k-th largest pooled value
 // (non-negative floats order like their bit patterns), then a second kernel writes the mask.
+// Round 4: one 256-bin histogram PER WAVE (16 KB of LDS), summed once per pass -- with one shared histogram the 1024 threads' LDS atomics of the
+// later passes serialised on the bins (3D, 62 720 pooled values per sample, 2 samples = 2 blocks: 88 us on the iteration's critical chain).
 __global__ __launch_bounds__(1024) void diffmask_select_kernel(const chap_diffmask_params P, float* thr_out) {
+    __shared__ unsigned whist[16][256];
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix;
     __shared__ int s_rem;
@@ -176,29 +179,47 @@ __global__ __launch_bounds__(1024) void diffmask_select_kernel(const chap_diffma
     int k = (int)(P.topk * (float)M);
     if (k < 1) k = 1;
     if (threadIdx.x == 0) { s_prefix = 0; s_rem = k; }
+    unsigned* myh = whist[threadIdx.x >> 6];
     for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
+        for (int i = threadIdx.x; i < 16 * 256; i += 1024) (&whist[0][0])[i] = 0;
         __syncthreads();
         const unsigned prefix = s_prefix;
         const unsigned himask = shift == 24 ? 0u : ~((1u << (shift + 8)) - 1u);
         const int Mpad = (M + 63) & ~63;                       // whole waves go through the loop (ballots)
-        for (int i = threadIdx.x; i < Mpad; i += 1024) {
-            float f = i < M ? v[i] : 0.f; if (f < 0.f) f = 0.f;
-            const unsigned u = __float_as_uint(f);
-            const bool hit = i < M && (u & himask) == prefix;
-            const unsigned bin = (u >> shift) & 255u;
-            if (shift == 24) {
-                // first pass: sign + exponent bits -- nearly every value falls into one or two bins, i.e. one LDS word takes every
-                // increment of the block.  One increment per distinct bin of a wave instead (a leader adds the group's count).
-                unsigned long long todo = __ballot(hit);
-                while (todo) {
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const unsigned lb = __shfl(bin, leader, 64);
-                    const unsigned long long same = __ballot(hit && bin == lb) & todo;
-                    if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lb], (unsigned)__popcll(same));
-                    todo &= ~same;
-                }
-            } else if (hit) atomicAdd(&hist[bin], 1u);
+        // four values per thread and trip, their loads issued together: one dependent load per trip left the two blocks of a 3D batch
+        // (62 720 pooled values per sample) at ~90 us, all of it load latency
+        for (int i0 = threadIdx.x; i0 < Mpad; i0 += 4 * 1024) {
+            float fv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int i = i0 + q * 1024; fv[q] = i < M ? v[i] : 0.f; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * 1024;
+                if (i - (int)threadIdx.x >= Mpad) break;            // wave-uniform: the trip's later quarters may lie beyond the padded end
+                float f = fv[q]; if (f < 0.f) f = 0.f;
+                const unsigned u = __float_as_uint(f);
+                const bool hit = i < M && (u & himask) == prefix;
+                const unsigned bin = (u >> shift) & 255u;
+                if (shift == 24) {
+                    // first pass: sign + exponent bits -- nearly every value falls into one or two bins, i.e. one LDS word takes every
+                    // increment of the block.  One increment per distinct bin of a wave instead (a leader adds the group's count).
+                    unsigned long long todo = __ballot(hit);
+                    while (todo) {
+                        const int leader = __ffsll((long long)todo) - 1;
+                        const unsigned lb = __shfl(bin, leader, 64);
+                        const unsigned long long same = __ballot(hit && bin == lb) & todo;
+                        if ((int)(threadIdx.x & 63) == leader) atomicAdd(&myh[lb], (unsigned)__popcll(same));
+                        todo &= ~same;
+                    }
+                } else if (hit) atomicAdd(&myh[bin], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            unsigned t = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) t += whist[w][threadIdx.x];
+            hist[threadIdx.x] = t;
         }
         __syncthreads();
         // the k-th largest lies in the bin t with  (values in bins above t) < rem <= (values in bins above t) + hist[t]: exactly one

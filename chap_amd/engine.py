@@ -121,6 +121,12 @@ def issue_interleaved(what=7):
     return bool(mask & what)
 
 
+def side_branch():
+    """CHAP_SIDE_DECODER (lab / A-B switch, default 2): which decoder of a forking pass runs on the forked stream (the other stays on the pass's own)."""
+    import os
+    return 1 if os.environ.get("CHAP_SIDE_DECODER", "2") == "1" else 2
+
+
 def split_concat_gradient():
     """CHAP_SPLIT_CONCAT (lab / A-B switch, default 1): the input gradient of a concat layer as two dense tensors (chap_conv_params.out2)."""
     import os
@@ -452,9 +458,9 @@ class Executor:
         for op in prog.ops:
             if op.branch == 0:
                 yield [lambda op=op: run_op(op)]
-        # One-shot hook between the trunk and the decoders: the caller issues ANOTHER chain's work here (ChapStep: the early VAT pass on its own
-        # stream).  Only the ISSUE ORDER changes -- the order in which a captured graph's nodes are created is the order in which a replay feeds
-        # them to the GPU (~3 us per node from the host), so work that is issued in one piece in front of a critical chain delays it.
+        # One-shot hook between the trunk and the decoders: the caller issues ANOTHER chain's work here (ChapStep, CHAP_ISSUE_INTERLEAVE & 2: the early
+        # VAT pass on its own stream).  Only the ISSUE ORDER changes, i.e. the creation order of a captured graph's nodes -- which decides how the ROCm
+        # graph executor places the chains on its queues (see issue_interleaved).
         hook, self.after_trunk = self.after_trunk, None
         if hook is not None:
             hook()
@@ -476,8 +482,8 @@ class Executor:
             for pair in zipped:
                 yield [lambda op=op: run_dec(op) for op in pair]
         elif side is not None:
-            # two streams; the ops of the two decoders are issued ALTERNATELY (aligned schedule), not one decoder after the other: both chains
-            # are fed at the host's node rate instead of the second one's ~25 nodes standing in front of the first one's (see the hook above)
+            # two streams: the second decoder's ops first, then the first one's (CHAP_ISSUE_INTERLEAVE & 4, round-4 experiment: alternately, op by op --
+            # neutral: 6.55 vs 6.5 ms)
             side.wait_stream(cur_stream)
             if len(branches) == 3 and issue_interleaved(4):
                 for pair in self._zipped():
@@ -488,12 +494,13 @@ class Executor:
                         else:
                             run_dec(op)
             else:
+                sb = side_branch()                  # which decoder goes to the forked stream (default: the second)
                 with torch.cuda.stream(side):
                     for op in prog.ops:
-                        if op.branch >= 2:
+                        if op.branch != 0 and (op.branch >= 2) == (sb == 2):
                             run_dec(op)
                 for op in prog.ops:
-                    if op.branch == 1:
+                    if op.branch != 0 and (op.branch >= 2) != (sb == 2):
                         run_dec(op)
             cur_stream.wait_stream(side)
         else:
@@ -712,12 +719,13 @@ class Executor:
                         else:
                             bwd_op(op)
             else:
+                sb = side_branch()
                 with torch.cuda.stream(side):
                     for op in rev:
-                        if op.branch >= 2:
+                        if op.branch != 0 and (op.branch >= 2) == (sb == 2):
                             bwd_op(op)
                 for op in rev:
-                    if op.branch == 1:
+                    if op.branch != 0 and (op.branch >= 2) != (sb == 2):
                         bwd_op(op)
             cur_stream.wait_stream(side)
             for op in rev:

@@ -372,12 +372,11 @@ class ChapStep:
         with self._decoder_fork(main):
             ctx = self._phase_a(volume_batch, label_batch, inject)
             if self.concurrent and self.args["adv_noise"]:
-                # Phase B (side stream) and phase V (this stream, the iteration's critical chain) are ISSUED pass by pass in alternation --
-                # V's power iteration, B's forward, V's final forward, B's backward, V's final backward.  The issue order is the order in which a
-                # captured graph's nodes are created, and a replay feeds the nodes to the GPU in that order at ~3 us per node from the host: with
-                # "all of phase B, then all of phase V" (rounds 1-3) the ~350 nodes of phase B were queued in front of phase V's first kernel, and
-                # the critical chain stood still for ~380 us after the fork (untraced timeline, profiles/r04_timeline_untraced_2d_before.json:
-                # diff_mask ends at 1410 us, the distance kernel behind it at 1788 us with nothing but phase B's first kernels in between).
+                # Phase B (side stream) and phase V (this stream, the iteration's critical chain).  Default: all of phase B is issued first, then phase V
+                # (the order of rounds 1-3).  CHAP_ISSUE_INTERLEAVE & 1 (round-4 experiment) issues them pass by pass in alternation -- V's power iteration,
+                # B's forward, V's final forward, B's backward, V's final backward: same launches, same streams, bit-identical results, and 8.05 ms per 2D step
+                # instead of 6.5: the ROCm 7.2 graph executor places the chains of a captured graph on its hardware queues by the creation order of the nodes,
+                # and in that order pass B lands on the VAT chain's queue and runs entirely after it ("Issue order").
                 self._side.wait_stream(main)
                 gen_v, gen_b = self._phase_v_steps(ctx), self._phase_b_steps(ctx)
                 losses = vat_loss = None
@@ -460,9 +459,8 @@ class ChapStep:
         model.prepare_weights()                  # before the streams fork: every pass of the iteration reads the same packed copies
         if a["adv_noise"]:
             if pre is not None:
-                # The early pass runs on its own stream beside pass A; it is ISSUED between pass A's encoder and its decoders (Executor.after_trunk):
-                # issued in one piece in front of pass A (rounds 2-3) its ~65 nodes were queued before pass A's first kernel in every replay of the
-                # captured graph and the iteration's critical chain started ~380 us late (profiles/r04_timeline_untraced_2d_before.json).
+                # The early pass runs on its own stream beside pass A and is issued in front of it.  CHAP_ISSUE_INTERLEAVE & 2 (round-4 experiment) issues it
+                # between pass A's encoder and its decoders (Executor.after_trunk) instead: measured slower (6.95 vs 6.5 ms: it then shares a queue with pass A).
                 pre.wait_stream(main)
 
                 def issue_early_pass():

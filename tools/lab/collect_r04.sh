@@ -51,13 +51,14 @@ for c in 2d 3d; do
     rm -rf $O/pmc_dom${c}_$k
     rocprofv3 --pmc $k --output-format csv -d $O/pmc_dom${c}_$k -- python3 $R/tools/dominant_kernel.py $a > $O/pmc_dom${c}_$k.log 2>&1
   done
-  (cd $R && python3 tools/pmc_traffic.py $O/pmc_dom${c}_FETCH_SIZE $O/pmc_dom${c}_WRITE_SIZE conv_fwd_kernel > $O/r04_pmc_traffic_dominant_$c.jsonl)
+  (cd $R && python3 tools/pmc_traffic.py $O/pmc_dom${c}_FETCH_SIZE $O/pmc_dom${c}_WRITE_SIZE conv_ > $O/r04_pmc_traffic_dominant_$c.jsonl)
 done
 echo "pmc done"
 fi
 if has timeline; then
 for c in 2d 3d; do
   (cd $R && CHAP_LIBPATH=tools/lab/libchap_hip_lab.so python3 tools/timeline_untraced.py --config $c --out $O/r04_timeline_untraced_$c.json > $O/timeline_$c.log 2>&1)
+  (cd $R && CHAP_LIBPATH=tools/lab/libchap_hip_lab.so python3 tools/timeline_untraced.py --config $c --steady 1 --out $O/r04_timeline_untraced_${c}_isolated.json > $O/timeline_${c}_isolated.log 2>&1)
 done
 echo "timelines done"
 fi
