@@ -197,7 +197,10 @@ __device__ __forceinline__ void halo_issue_impl(halo_regs<T, UNITS, ADD2, !D3>& 
     const bool second = (ADD2 || ONE) ? false : (LANESEL ? (cb + U.c8 >= s0.C) : (cb >= s0.C));
     const int cs = second ? cb - s0.C : cb;                      // first channel of the chunk inside the source (can be < 0 for LANESEL lanes of s1: + c8 >= 0)
     const int ld = second ? s1.ld : s0.ld;
-    const char* base = (const char*)(second ? s1.ptr : s0.ptr) + (gp0 * ld + (second ? s1.coff : s0.coff) + cs) * (long)sizeof(T);
+    // (s0.ptr + (second ? s1.ptr - s0.ptr : 0), not second ? s1.ptr : s0.ptr: the compiler turns a select of the two loaded pointers into a load
+    //  from a selected address, which pins both in scratch -- 24 B per lane and two scratch loads per tile in the 3D weight-gradient kernels)
+    const long dptr = (const char*)s1.ptr - (const char*)s0.ptr;
+    const char* base = (const char*)s0.ptr + (second ? dptr : 0l) + (gp0 * ld + (second ? s1.coff : s0.coff) + cs) * (long)sizeof(T);
     const unsigned ldb = ld * sizeof(T), lane_c = U.c8 * sizeof(T);
     unsigned okm = 0, r[UNITS];
 #pragma unroll

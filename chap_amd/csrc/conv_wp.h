@@ -22,7 +22,7 @@ __host__ __device__ constexpr size_t conv_wp_lds_bytes() {
     constexpr int GPT = KC / 8, NP = G::NTAPS * GPT, STEPS = (NP + 3) / 4;
     return (size_t)STEPS * NT * 512 * sizeof(bf16_t)                                            // the block's weights, fragment order
            + 4 * ((size_t)G::HP * pix_stride<bf16_t, KC>() + HALO_DUMMY) * sizeof(bf16_t)       // one halo region per wave
-           + 4 * 2 * 16 * NT * sizeof(float) + 2 * CWP_AFFC * sizeof(float);
+           + 4 * 2 * 16 * NT * sizeof(float) + 2 * CWP_AFFC * sizeof(float) + 2 * 16 * NT * sizeof(float);
 }
 
 // runs behind chap_grouped<chap_conv_params, .., 256, MINW>; grid (blocks, ceil(Cout / (16 NT)))
@@ -36,12 +36,14 @@ __device__ __forceinline__ void conv_wp_kernel(const chap_conv_params& P) {
     constexpr int UNITS = (G::HP * GPT + 63) / 64;
     constexpr int ROWS = G::TH;
     constexpr size_t HB = (size_t)G::HP * PS + HALO_DUMMY;
+    static_assert((HB * sizeof(T)) % 16 == 0, "the float4 reads of bc need a 16-byte aligned tail");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     T* wlds = (T*)smem;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     T* halo = wlds + (size_t)STEPS * NT * 512 + wave * HB;
     float* bstat = (float*)(wlds + (size_t)STEPS * NT * 512 + 4 * HB);
     float* aff = bstat + 4 * 2 * 16 * NT;
+    float* bc = aff + 2 * CWP_AFFC;                             // bias | statistics shift of this block's 16 NT output channels (0 where absent)
     const int px = lane & 15, g = lane >> 4;
     const int tiles_x = (P.W + G::TW - 1) / G::TW, tiles_y = (P.H + G::TH - 1) / G::TH;
     const long ntiles = (long)P.N * tiles_y * tiles_x;
@@ -96,41 +98,30 @@ __device__ __forceinline__ void conv_wp_kernel(const chap_conv_params& P) {
         const unsigned tt = nt0 + (int)t < ntiles_total ? t : 0u;
         wreg[k] = frag<T>::load((const T*)P.wpacked + (long)step * wstep + ((long)(nt0 + tt) * 64 + ln) * 8);
     }
-    float ssum[NT][4], ssq[NT][4], bj[NT][4], cj[NT][4];
-    {
-        const float* bsrc = P.bias ? P.bias : (const float*)P.wpacked;
-        const bool has_shift = do_stats && P.stats_shift != nullptr;
-        const float* csrc = has_shift ? P.stats_shift : (const float*)P.wpacked;
+    float ssum[NT][4], ssq[NT][4];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int nl = (nt0 + t) * 16 + 4 * g;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ssum[t][j] = 0.f; ssq[t][j] = 0.f;
-                bj[t][j] = bsrc[(P.bias && nl + j < P.Cout) ? nl + j : 0];
-                cj[t][j] = csrc[(has_shift && nl + j < P.Cout) ? nl + j : 0];
-            }
-        }
+        for (int j = 0; j < 4; ++j) { ssum[t][j] = 0.f; ssq[t][j] = 0.f; }
+    // bias and statistics shift live in LDS and are re-read per tile (two ds_read_b128): held in registers they pushed the 128-VGPR variant into
+    // scratch (32 B per lane = 8 MB of HBM writes per launch of the 16->16 layer, PMC: profiles/r04_pmc_traffic_dominant_2d.jsonl)
+    float bcv = 0.f;
+    if (threadIdx.x < 2 * 16 * NT) {
+        const int which = threadIdx.x / (16 * NT), nl = nt0 * 16 + (int)threadIdx.x % (16 * NT);
+        const float* srcp = which == 0 ? P.bias : (do_stats ? P.stats_shift : nullptr);
+        if (srcp != nullptr && nl < P.Cout) bcv = srcp[nl];
     }
     if (threadIdx.x < 64) {
         const int s_ = threadIdx.x >> 5, c = threadIdx.x & 31;
         aff[s_ * CWP_AFFC + c] = asc[0]; aff[s_ * CWP_AFFC + CWP_AFFC / 2 + c] = ash[0];
     }
+    if (threadIdx.x < 2 * 16 * NT) bc[threadIdx.x] = bcv;
 #pragma unroll
     for (int k = 0; k < WPT; ++k) {
         const unsigned i = threadIdx.x + 256 * k;
         if (i < (unsigned)(STEPS * NT * 64)) {
             const unsigned t = (i >> 6) % (unsigned)NT;
             frag<T>::store(wlds + (size_t)i * 8, (nt0 + (int)t < ntiles_total) ? wreg[k] : frag<T>::zero());
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int nl = (nt0 + t) * 16 + 4 * g;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            bj[t][j] = (P.bias && nl + j < P.Cout) ? bj[t][j] : 0.f;
-            cj[t][j] = (do_stats && P.stats_shift != nullptr && nl + j < P.Cout) ? cj[t][j] : 0.f;
         }
     }
     int xoff[STEPS];                                            // LDS element offset of this lane's pixel fragment (row 0), -1 = zero fragment
@@ -186,15 +177,17 @@ __device__ __forceinline__ void conv_wp_kernel(const chap_conv_params& P) {
                 for (int t = 0; t < NT; ++t) {
                     const bool cok = (nt0 + t) * 16 + 4 * g < P.Cout;
                     char* obt = (P.out2 && (nt0 + t) * 16 >= P.out2_from) ? ob2 : ob;
+                    const float4 b4 = *(const float4*)(bc + t * 16 + 4 * g), c4 = *(const float4*)(bc + 16 * NT + t * 16 + 4 * g);
+                    const float bj[4] = {b4.x, b4.y, b4.z, b4.w}, cj[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
                     for (int m = 0; m < ROWS; ++m) {
                         const bool valid = xok && cok && (y0 + m < P.H);
                         float v[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = acc[m][t][j] + bj[t][j];
+                        for (int j = 0; j < 4; ++j) v[j] = acc[m][t][j] + bj[j];
                         if (do_stats) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) { const float d = valid ? v[j] - cj[t][j] : 0.f; ssum[t][j] += d; ssq[t][j] += d * d; }
+                            for (int j = 0; j < 4; ++j) { const float d = valid ? v[j] - cj[j] : 0.f; ssum[t][j] += d; ssq[t][j] += d * d; }
                         }
                         if (valid) st4((T*)(obt + (unsigned)(m * orow + ooff[t]) * (unsigned)sizeof(T)), v);
                     }

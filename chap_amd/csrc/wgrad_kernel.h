@@ -118,7 +118,8 @@ __device__ __forceinline__ void wgrad_kernel(const wgrad_args& A, int nb) {     
         }
     }
     // affine caches
-    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {                                 // (unrolled: a runtime index into the argument block puts its pointers in scratch)
         const chap_src_t& src = s == 2 ? P.b : P.a[s < P.na ? s : 0];
         const bool has = src.scale != nullptr;
         for (int c = threadIdx.x; c < src.C && c < AFFC / 2; c += 256) {

@@ -122,9 +122,11 @@ def issue_interleaved(what=7):
 
 
 def side_branch():
-    """CHAP_SIDE_DECODER (lab / A-B switch, default 2): which decoder of a forking pass runs on the forked stream (the other stays on the pass's own)."""
+    """CHAP_SIDE_DECODER (lab / A-B switch, default 1): which decoder of a forking pass runs on the forked stream (the other stays on the pass's
+    own).  Round 4, two runs each: 2D 6.413 / 6.421 ms with decoder 2 on the fork, 6.385 / 6.407 with decoder 1; 3D 14.82 / 14.70 vs 14.66 / 14.62
+    (profiles/r04_side_decoder_ab.log)."""
     import os
-    return 1 if os.environ.get("CHAP_SIDE_DECODER", "2") == "1" else 2
+    return 2 if os.environ.get("CHAP_SIDE_DECODER", "1") == "2" else 1
 
 
 def split_concat_gradient():
@@ -555,6 +557,23 @@ class Executor:
             spos[0] += n
             return t
 
+        # in-launch totals (csrc/tail.h): ticket words of every layer zeroed by ONE fill at the start of the pass, fp64 group rows beside them
+        tail_on = ops.in_launch_totals()
+        if tail_on:
+            nbn_ops = sum(1 for op in prog.ops if op.bn)
+            tickets_arena = L.hold(torch.zeros(max(nbn_ops, 1) * L.TAIL_TICKETS, dtype=torch.int32, device=dev))
+            trows_arena = L.hold_empty(sum(ops.tail_rows_size(2 * op.cout) for op in prog.ops if op.bn) or 1, dtype=torch.float64, device=dev)
+        tpos = [0, 0]
+
+        def take_tail(c):
+            if not tail_on:
+                return None
+            n = ops.tail_rows_size(2 * c)
+            t = (tickets_arena[tpos[0]:tpos[0] + L.TAIL_TICKETS], trows_arena[tpos[1]:tpos[1] + n])
+            tpos[0] += L.TAIL_TICKETS
+            tpos[1] += n
+            return t
+
         def scatter(op, srcs, dsrc):
             muls = S.fold.get(op.branch) if S.tables is not None else None
             if not muls:
@@ -629,6 +648,7 @@ class Executor:
                             kw.update(dgamma=gr[op.bn + ".weight"], dbeta=gr[op.bn + ".bias"])
                     if op.bn:
                         kw["sums"] = take_sums(v.C)
+                        kw["tail"] = take_tail(v.C)
                     ops.act_bwd(v, c or [], gout, g_pool=pl[0] if pl else None, pool_idx=pl[1] if pl else None, **kw)
                     g = Lazy(gout)
             # ---- this conv's own backward

@@ -225,10 +225,12 @@ def _act_bwd_params(lazy, grads, g_pool, pool_idx, mean, invstd, gamma, sums, go
 
 
 def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=None, gamma=None,
-            dgamma=None, dbeta=None, count=1.0, bn_mode=None, sums=None):
+            dgamma=None, dbeta=None, count=1.0, bn_mode=None, sums=None, tail=None):
     """grads: list of (tensor, channel offset).
     bn_mode 1 (default when mean is given): training-mode BN backward fused in;
-    bn_mode 2: fixed affine (eval-mode BN), dgamma/dbeta from the same reduction when requested."""
+    bn_mode 2: fixed affine (eval-mode BN), dgamma/dbeta from the same reduction when requested.
+    tail: (tickets, rows) from `tail_buffers` -- the reduce launch totals its own partial rows (csrc/tail.h) instead of a second kernel;
+    the tickets must be ZERO when the launch starts."""
     if bn_mode is None:
         bn_mode = 1 if mean is not None else 0
     need_reduce = bn_mode == 1 or (bn_mode == 2 and (dgamma is not None or dbeta is not None))
@@ -236,10 +238,25 @@ def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=
         sums = L.hold_empty(act_bwd_sums_size(lazy.C), dtype=torch.float32, device=gout.device)
     p = _act_bwd_params(lazy, grads, g_pool, pool_idx, mean, invstd, gamma, sums, gout, dgamma, dbeta, count)
     p.bn = bn_mode
+    if tail is not None and need_reduce:
+        assert tail[0].dtype == torch.int32 and tail[0].numel() >= L.TAIL_TICKETS and tail[1].dtype == torch.float64 and tail[1].numel() >= tail_rows_size(2 * lazy.C)
+        p.tail_tickets, p.tail_rows = tail[0].data_ptr(), tail[1].data_ptr()
     if need_reduce:
         L.call("chap_act_bwd_reduce", p, _stream())
     L.call("chap_act_bwd_apply", p, _stream())
     return sums
+
+
+def tail_rows_size(width):
+    """doubles of the second-level scratch of an in-launch total over rows of `width` floats (csrc/tail.h)."""
+    return L.TAIL_GROUPS * width
+
+
+def in_launch_totals():
+    """CHAP_TAIL (A/B switch, default 1): BatchNorm statistics and BatchNorm-backward sums are totalled by the launch that produces them (the block
+    that arrives last finishes: csrc/tail.h) instead of by bn_finalize / act_bwd_sum launches."""
+    import os
+    return os.environ.get("CHAP_TAIL", "1") != "0"
 
 
 def act_bwd_sums_size(c):

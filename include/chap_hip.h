@@ -53,9 +53,12 @@
 extern "C" {
 #endif
 
-#define CHAP_ABI_VERSION 7
+#define CHAP_ABI_VERSION 8
 #define CHAP_STATS_MAX_SLOTS 1024  /* per-block partial slots of the BatchNorm statistics (one per persistent conv block) */
 #define CHAP_STATS_HDR 4           /* floats in front of the slots; word 0 = number of slots in use (int32)                */
+#define CHAP_TAIL_GROUP   32      /* in-launch totals (csrc/tail.h): partial rows per first-level group ...                  */
+#define CHAP_TAIL_GROUPS  32      /* ... groups (32 x 32 = 1024 rows = CHAP_STATS_MAX_SLOTS = CHAP_ACT_BWD_SLOTS)            */
+#define CHAP_TAIL_TICKETS 64      /* int32 ticket words per launch: [0] second level, [1 + g] group g; the rest padding      */
 #define CHAP_ACT_BWD_SLOTS 1024    /* per-block partial slots of the BN-backward sums                                      */
 #define CHAP_LOSS_SLOTS 512        /* per-block partial rows of the loss accumulators                                      */
 #define CHAP_CHANSUM_SLOTS 512
@@ -122,6 +125,9 @@ typedef struct {
     void*       out2;          /* input gradient of a layer whose input was torch.cat((a, b), 1) (unet.py:98) as two DENSE tensors: the consumers of a  */
                                /* half (BatchNorm backward) read whole sectors instead of a 16-channel slice of 32-channel rows.  Same out_ld / out_coff; */
                                /* out_mode 0, channel-last, out2_from % 16 == 0; NULL = off                                                             */
+#ifdef CHAP_CONV_PAD           /* lab builds only (kernel-argument size experiment, tools/lab): never defined in the product build */
+    char        lab_pad[CHAP_CONV_PAD];
+#endif
 } chap_conv_params;
 
 int chap_conv_fwd(const chap_conv_params* p, void* stream);
@@ -247,6 +253,10 @@ typedef struct {
     float* dgamma; float* dbeta;                     /* accumulated (+=)                          */
     int32_t N, D, H, W;  int32_t bn;  /* 0 none, 1 training-mode BN, 2 fixed affine (eval BN): g = dz*scale */
     float count;  int32_t dtype;
+    /* ABI 8, in-launch totals (csrc/tail.h): with both set, chap_act_bwd_reduce is ONE launch -- the block that arrives last totals the partial rows,
+     * writes row 0 and accumulates dgamma / dbeta itself (no second kernel).  NULL = the two-launch form. */
+    int32_t* tail_tickets;  /* CHAP_TAIL_TICKETS int32, ZERO when the launch starts (the caller zeroes them: one memset for all layers of a pass)        */
+    double*  tail_rows;     /* CHAP_TAIL_GROUPS x 2C fp64 scratch, nothing to zero                                                                        */
 } chap_act_bwd_params;
 int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream);
 int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream);
