@@ -25,6 +25,11 @@ class Src(C.Structure):
                 ("C", _i32), ("ld", _i32), ("coff", _i32), ("act", _i32), ("slope", _f32), ("keep_scale", _f32)]
 
 
+class BnFin(C.Structure):           # chap_bn_fin_t
+    _fields_ = [("tickets", _vp), ("rows", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
+                ("num_batches_tracked", _vp), ("affine", _vp), ("C", _i32), ("count", _f32), ("eps", _f32), ("momentum", _f32)]
+
+
 class ConvParams(C.Structure):
     _fields_ = [("src", Src * 2), ("nsrc", _i32), ("combine", _i32),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("ID", _i32), ("IH", _i32), ("IW", _i32),
@@ -32,7 +37,7 @@ class ConvParams(C.Structure):
                 ("wpacked", _vp), ("bias", _vp), ("out", _vp),
                 ("Cout", _i32), ("out_ld", _i32), ("out_coff", _i32), ("out_mode", _i32), ("out_Cn", _i32),
                 ("out_planar", _i32), ("out_f32", _i32),
-                ("stats", _vp), ("stats_shift", _vp), ("dtype", _i32), ("out2_from", _i32), ("out2", _vp)] + (
+                ("stats", _vp), ("stats_shift", _vp), ("dtype", _i32), ("out2_from", _i32), ("out2", _vp), ("fin", BnFin)] + (
                     [("lab_pad", C.c_char * int(os.environ["CHAP_CONV_PAD"]))] if os.environ.get("CHAP_CONV_PAD") else [])      # lab builds (-DCHAP_CONV_PAD=n)
 
 

@@ -53,7 +53,10 @@ __device__ __forceinline__ bool tail_total(const float* rows, int W, int nrows, 
     for (int v = threadIdx.x; v < W; v += THREADS) {
         float x[CHAP_TAIL_GROUP];
 #pragma unroll
-        for (int i = 0; i < CHAP_TAIL_GROUP; ++i) x[i] = tail_load(rows + (long)(r0 + (i < rn ? i : 0)) * W + v);
+        for (int i = 0; i < CHAP_TAIL_GROUP; ++i) {              // (uniform row pointer + one 32-bit lane offset: no 64-bit address per load)
+            const float* rp = rows + (long)(r0 + (i < rn ? i : 0)) * W;
+            x[i] = tail_load(rp + (unsigned)v);
+        }
         double s = 0.0;
 #pragma unroll
         for (int i = 0; i < CHAP_TAIL_GROUP; ++i) s += i < rn ? (double)x[i] : 0.0;
@@ -69,7 +72,10 @@ __device__ __forceinline__ bool tail_total(const float* rows, int W, int nrows, 
     for (int v = threadIdx.x; v < W; v += THREADS) {
         double x[CHAP_TAIL_GROUPS];
 #pragma unroll
-        for (int g = 0; g < CHAP_TAIL_GROUPS; ++g) x[g] = tail_load(grows + (long)(g < ngroups ? g : 0) * W + v);
+        for (int g = 0; g < CHAP_TAIL_GROUPS; ++g) {
+            const double* gp = grows + (long)(g < ngroups ? g : 0) * W;
+            x[g] = tail_load(gp + (unsigned)v);
+        }
         double s = 0.0;
 #pragma unroll
         for (int g = 0; g < CHAP_TAIL_GROUPS; ++g) s += g < ngroups ? x[g] : 0.0;
@@ -77,4 +83,58 @@ __device__ __forceinline__ bool tail_total(const float* rows, int W, int nrows, 
     }
     __syncthreads();
     return true;
+}
+
+// ---- BatchNorm finalize by the last block of a conv launch (chap_conv_params.fin): what bn_finalize_kernel does, from the fp64 totals.
+// tot: [2][Clog] (sum(x - c), sum((x - c)^2) per LOGICAL channel; the sub-lattice rows of a transposed conv, Clog = nsub x C, are folded here)
+template <int THREADS>
+__device__ __forceinline__ void bn_finalize_from_totals(const chap_bn_fin_t& F, const double* tot, int Clog, const float* stats_shift) {
+    const int C = F.C, nsub = Clog / C;
+    const bool upd = F.momentum > 0.f && F.running_mean != nullptr;
+    for (int c = threadIdx.x; c < C; c += THREADS) {
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < nsub; ++k) { s += tot[k * C + c]; q += tot[Clog + k * C + c]; }
+        const double cnt = (double)F.count;
+        const double ms = s / cnt;                               // mean of (x - shift)
+        double var = q / cnt - ms * ms;
+        var = var > 0.0 ? var : 0.0;
+        const float mean = (float)((double)(stats_shift ? stats_shift[c] : 0.f) + ms);
+        const float invstd = (float)(1.0 / sqrt(var + (double)F.eps));
+        const float sc = F.gamma[c] * invstd;
+        F.affine[c] = sc;
+        F.affine[C + c] = F.beta[c] - mean * sc;
+        F.affine[2 * C + c] = mean;
+        F.affine[3 * C + c] = invstd;
+        if (upd) {
+            const float unb = (float)(cnt > 1.0 ? var * cnt / (cnt - 1.0) : var);
+            F.running_mean[c] = (1.f - F.momentum) * F.running_mean[c] + F.momentum * mean;
+            F.running_var[c] = (1.f - F.momentum) * F.running_var[c] + F.momentum * unb;
+        }
+    }
+    if (threadIdx.x == 0 && F.num_batches_tracked && F.momentum > 0.f) *F.num_batches_tracked += 1;
+}
+
+// LDS the last block needs (fp64 totals + the flag); the launchers request at least this much
+static inline size_t conv_fin_lds_bytes(const chap_conv_params* p) { return p->fin.tickets ? (size_t)2 * p->Cout * sizeof(double) + 16 : 0; }
+
+// The end of every statistics-producing conv kernel: the block's partial slot from the four waves' LDS rows (bstat: [4 waves][2][16 NT], already
+// behind a barrier), and with P.fin the in-launch finalize.  smem: the block's dynamic LDS (free by now: tail_total opens with a barrier).
+template <int NT>
+__device__ __forceinline__ void conv_stats_store(const chap_conv_params& P, const float* bstat, int nt0, char* smem) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(int*)P.stats = (int)gridDim.x;      // header: slots in use
+    // slot rows are indexed by the LOGICAL channel (a transposed conv's sub-lattices are folded by the finalize)
+    float* st = P.stats + CHAP_STATS_HDR + (long)blockIdx.x * 2 * P.Cout;
+    const bool tail = P.fin.tickets != nullptr;
+    for (int i = threadIdx.x; i < 2 * 16 * NT; i += 256) {
+        const int which = i / (16 * NT), k = i % (16 * NT);
+        const int nl = nt0 * 16 + k;
+        const float v = (bstat[(0 * 2 + which) * 16 * NT + k] + bstat[(1 * 2 + which) * 16 * NT + k]) + (bstat[(2 * 2 + which) * 16 * NT + k] + bstat[(3 * 2 + which) * 16 * NT + k]);
+        if (nl < P.Cout) { if (tail) tail_store(st + which * P.Cout + nl, v); else st[which * P.Cout + nl] = v; }
+    }
+    if (tail) {
+        double* tot = (double*)smem;
+        int* flag = (int*)(tot + 2 * P.Cout);
+        if (tail_total<256>(P.stats + CHAP_STATS_HDR, 2 * P.Cout, (int)gridDim.x, (int)blockIdx.x, (int)gridDim.y, P.fin.tickets, P.fin.rows, tot, flag))
+            bn_finalize_from_totals<256>(P.fin, tot, P.Cout, P.stats_shift);
+    }
 }

@@ -42,6 +42,8 @@
  *      stream: +15-22 % step time), the "lazy gradient" chap_bgrad_t of chap_wgrad (+0.8 / +2.7 %), the deferred multi-layer slab reduction
  *      (+-0 / +1 %); measurements in DESIGN.md section 5.  chap_conv_params.out2 / out2_from (a concat layer's input gradient as two dense
  *      tensors).
+ *   8  in-launch totals (csrc/tail.h): chap_conv_params.fin (BatchNorm finalize by the conv launch's last block), chap_act_bwd_params.tail_tickets /
+ *      tail_rows (BatchNorm-backward totals by the reduce launch's last block); CHAP_TAIL_*.
  */
 #ifndef CHAP_HIP_H
 #define CHAP_HIP_H
@@ -99,6 +101,19 @@ typedef struct {
  *                 E[x^2] - E[x]^2; NULL = 0).  Buffer: CHAP_STATS_HDR + CHAP_STATS_MAX_SLOTS * 2 * Cout floats.
  *                 chap_bn_finalize sums the slots in a fixed order: bitwise reproducible for a given launch geometry.
  */
+/* ABI 8 -- BatchNorm finalize INSIDE the launch that produces the statistics (csrc/tail.h).  The conv's blocks store their partial slots as
+ * before; the block that arrives last (two ticket levels, CHAP_TAIL_GROUP slots per group) totals them in fp64 in a fixed order and does what
+ * chap_bn_finalize does: scale / shift of the lazy activation, saved mean / invstd, running statistics.  One launch and one launch gap less on
+ * the dependency chain per BatchNorm layer (~150 of the ~740 launches of a 2D training iteration, with the BatchNorm-backward totals). */
+typedef struct {
+    int32_t* tickets;          /* CHAP_TAIL_TICKETS int32, ZERO when the launch starts (the caller zeroes them: one memset per pass); NULL = off */
+    double*  rows;             /* CHAP_TAIL_GROUPS x 2 x Cout fp64 scratch, nothing to zero                                                     */
+    const float* gamma;  const float* beta;
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;     /* as chap_bn_finalize_params (NULL / momentum 0: not updated)   */
+    float* affine;             /* out [4][C]: scale, shift, mean, invstd                                                                        */
+    int32_t C;  float count;  float eps;  float momentum;                      /* C real channels (Cout = C x sub-positions of a transposed conv) */
+} chap_bn_fin_t;
+
 typedef struct {
     chap_src_t  src[2];
     int32_t     nsrc;          /* 1 or 2                                                          */
@@ -125,6 +140,7 @@ typedef struct {
     void*       out2;          /* input gradient of a layer whose input was torch.cat((a, b), 1) (unet.py:98) as two DENSE tensors: the consumers of a  */
                                /* half (BatchNorm backward) read whole sectors instead of a 16-channel slice of 32-channel rows.  Same out_ld / out_coff; */
                                /* out_mode 0, channel-last, out2_from % 16 == 0; NULL = off                                                             */
+    chap_bn_fin_t fin;         /* ABI 8: BatchNorm finalize inside this launch (fin.tickets != NULL; needs stats): no chap_bn_finalize call follows       */
 #ifdef CHAP_CONV_PAD           /* lab builds only (kernel-argument size experiment, tools/lab): never defined in the product build */
     char        lab_pad[CHAP_CONV_PAD];
 #endif
