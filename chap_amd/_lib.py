@@ -13,7 +13,6 @@ LIB_PATH = os.environ.get("CHAP_LIBPATH") or os.path.join(_HERE, "libchap_hip.so
 F32, BF16 = 0, 1
 STATS_MAX_SLOTS, STATS_HDR = 1024, 4          # CHAP_STATS_MAX_SLOTS, CHAP_STATS_HDR
 ACT_BWD_SLOTS = 1024                           # CHAP_ACT_BWD_SLOTS
-TAIL_GROUP, TAIL_GROUPS, TAIL_TICKETS = 32, 32, 64      # CHAP_TAIL_GROUP, CHAP_TAIL_GROUPS, CHAP_TAIL_TICKETS (in-launch totals, csrc/tail.h)
 LOSS_SLOTS, CHANSUM_SLOTS, L2NORM_SLOTS = 512, 512, 256
 PACK_CONV_FWD, PACK_CONV_DGRAD, PACK_DECONV_FWD, PACK_DECONV_DGRAD, PACK_DOWN_DGRAD = range(5)
 
@@ -25,11 +24,6 @@ class Src(C.Structure):
                 ("C", _i32), ("ld", _i32), ("coff", _i32), ("act", _i32), ("slope", _f32), ("keep_scale", _f32)]
 
 
-class BnFin(C.Structure):           # chap_bn_fin_t
-    _fields_ = [("tickets", _vp), ("rows", _vp), ("gamma", _vp), ("beta", _vp), ("running_mean", _vp), ("running_var", _vp),
-                ("num_batches_tracked", _vp), ("affine", _vp), ("C", _i32), ("count", _f32), ("eps", _f32), ("momentum", _f32)]
-
-
 class ConvParams(C.Structure):
     _fields_ = [("src", Src * 2), ("nsrc", _i32), ("combine", _i32),
                 ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("ID", _i32), ("IH", _i32), ("IW", _i32),
@@ -37,8 +31,7 @@ class ConvParams(C.Structure):
                 ("wpacked", _vp), ("bias", _vp), ("out", _vp),
                 ("Cout", _i32), ("out_ld", _i32), ("out_coff", _i32), ("out_mode", _i32), ("out_Cn", _i32),
                 ("out_planar", _i32), ("out_f32", _i32),
-                ("stats", _vp), ("stats_shift", _vp), ("dtype", _i32), ("out2_from", _i32), ("out2", _vp), ("fin", BnFin)] + (
-                    [("lab_pad", C.c_char * int(os.environ["CHAP_CONV_PAD"]))] if os.environ.get("CHAP_CONV_PAD") else [])      # lab builds (-DCHAP_CONV_PAD=n)
+                ("stats", _vp), ("stats_shift", _vp), ("dtype", _i32), ("out2_from", _i32), ("out2", _vp)]
 
 
 class PackParams(C.Structure):
@@ -86,8 +79,7 @@ class ActBwdParams(C.Structure):
                 ("g_pool", _vp), ("pool_idx", _vp), ("r", Src),
                 ("mean", _vp), ("invstd", _vp), ("gamma", _vp), ("sums", _vp), ("gout", _vp),
                 ("dgamma", _vp), ("dbeta", _vp),
-                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("bn", _i32), ("count", _f32), ("dtype", _i32),
-                ("tail_tickets", _vp), ("tail_rows", _vp)]
+                ("N", _i32), ("D", _i32), ("H", _i32), ("W", _i32), ("bn", _i32), ("count", _f32), ("dtype", _i32)]
 
 
 class PoolParams(C.Structure):
@@ -227,7 +219,7 @@ _SIZE_FNS = {"chap_pack_size": PackParams, "chap_conv_c1_bwd_ws": ConvC1BwdParam
 _lib = None
 
 
-ABI_VERSION = 8            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
+ABI_VERSION = 7            # CHAP_ABI_VERSION of include/chap_hip.h this binding mirrors (checked when the library is loaded)
 
 
 class ChapError(RuntimeError):

@@ -96,12 +96,6 @@ extern "C" int chap_conv_fwd(const chap_conv_params* p, void* stream) {
     if (!p->out_planar) CHAP_CHECK_ARG(p->out_ld % 4 == 0 && p->out_coff % 4 == 0, "chap_conv_fwd: out_ld/out_coff must be multiples of 4");
     if (p->out2) CHAP_CHECK_ARG(p->out_mode == 0 && !p->out_planar && !p->out_f32 && (p->Cout & 3) == 0 && p->out2_from > 0 && p->out2_from % 16 == 0 && p->out2_from < p->Cout &&
                                 p->ksize == 3 && p->stride == 1, "chap_conv_fwd: out2 needs a channel-last k3 s1 output, out2_from %% 16 == 0 inside (0, Cout)");
-    if (p->fin.tickets) {            // BatchNorm finalize inside this launch (tail.h)
-        const chap_bn_fin_t& f = p->fin;
-        CHAP_CHECK_ARG(p->stats && f.rows && f.gamma && f.beta && f.affine && f.C > 0 && p->Cout % f.C == 0 && f.count > 0.f,
-                       "chap_conv_fwd: fin needs stats, rows, gamma, beta, affine, C dividing Cout, count > 0");
-        CHAP_CHECK_ARG((f.running_mean == nullptr) == (f.running_var == nullptr), "chap_conv_fwd: fin.running_mean and running_var come together");
-    }
     const int Ck = p->combine == 0 ? p->src[0].C + (p->nsrc > 1 ? p->src[1].C : 0) : p->src[0].C;
     const int taps = p->ksize * p->ksize * (p->dims == 3 ? p->ksize : 1);
     conv_blocking b = blocking_for(Ck, taps, p->Cout, p->dtype);

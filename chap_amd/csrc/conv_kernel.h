@@ -15,7 +15,6 @@
 // registers across tiles and flushed once per block into that block's partial slot (no atomics).
 #pragma once
 #include "common.h"
-#include "tail.h"
 #include "launch.h"
 #include <type_traits>
 
@@ -320,7 +319,7 @@ __device__ __forceinline__ void halo_commit_impl(const halo_regs<T, UNITS, ADD2,
     // They are >= 0: cm * leaky(a x + b) = leaky((cm a) x + cm b)
     if (LANESEL ? (s0.has_cm || s1.has_cm) : hcm) {
         // (the compiler hoists chan_mul + c8 out of the tile loop as a 64-bit per-lane pointer: two VGPRs held across the loop for a path that is
-        //  rarely taken, which tipped conv_wp_kernel<16,1>, exactly on its 128-VGPR cap, into scratch)
+        //  rarely taken -- conv_wp_kernel<16,1> sits exactly on its 128-VGPR cap and any extra live value there goes to scratch)
         const int cs = second ? cb - s0.C : cb;
         const float* cpu = second ? s1.chan_mul + (long)n * s1.C + cs : s0.chan_mul + (long)n * s0.C + cs;
         unsigned c8o = (unsigned)U.c8;
@@ -806,7 +805,14 @@ __device__ __forceinline__ void conv_fwd_kernel(const chap_conv_params& P) {
             }
         }
         __syncthreads();
-        conv_stats_store<NT>(P, bstat, nt0, smem);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(int*)P.stats = (int)gridDim.x;      // header: slots in use
+        float* st = P.stats + CHAP_STATS_HDR + (long)blockIdx.x * 2 * P.Cout;      // slot rows are indexed by the LOGICAL channel (a transposed conv's sub-lattices are folded by the finalize)
+        for (int i = threadIdx.x; i < 2 * 16 * NT; i += 256) {
+            const int which = i / (16 * NT), k = i % (16 * NT);
+            const int nl = nt0 * 16 + k;
+            const float v = (bstat[(0 * 2 + which) * 16 * NT + k] + bstat[(1 * 2 + which) * 16 * NT + k]) + (bstat[(2 * 2 + which) * 16 * NT + k] + bstat[(3 * 2 + which) * 16 * NT + k]);
+            if (nl < P.Cout) st[which * P.Cout + nl] = v;
+        }
     }
     CHAP_STAMP_P(5);
 }

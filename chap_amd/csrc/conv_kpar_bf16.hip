@@ -8,7 +8,6 @@ static int kpar_launch(const chap_conv_params* p, hipStream_t stream) {
     typedef conv_geom<3, 1, D3, D3 ? 1 : 2> G;
     const void* kern = chap_kernel<chap_conv_params, conv_kpar_kernel<bf16_t, D3, KC, NT, CPAR, ONE>, 256, 2>();
     const size_t lds = conv_kpar_lds_bytes<bf16_t, D3, KC, CPAR>(NT);
-    if (conv_fin_lds_bytes(p) > lds) { chap_set_error("conv(kpar): %zu B of LDS for the in-launch finalize, the kernel has %zu", conv_fin_lds_bytes(p), lds); return CHAP_EUNSUPPORTED; }
     static std::atomic<int> attr_set[16];                       // per device; setting the attribute twice (a race) is harmless
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
@@ -32,7 +31,6 @@ static int kpar2d_launch(const chap_conv_params* p, hipStream_t stream) {
     constexpr int NT = 2;
     const void* kern = chap_kernel<chap_conv_params, conv_kpar2d_kernel<NT, CPAR, ONE, KEEPM, SINGLE>, 256, 2>();
     const size_t lds = conv_kpar_lds_bytes<bf16_t, false, 32, CPAR>(NT);
-    if (conv_fin_lds_bytes(p) > lds) { chap_set_error("conv(kpar2d): %zu B of LDS for the in-launch finalize, the kernel has %zu", conv_fin_lds_bytes(p), lds); return CHAP_EUNSUPPORTED; }
     static std::atomic<int> attr_set[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;

@@ -211,6 +211,13 @@ __device__ __forceinline__ void conv_wp_kernel(const chap_conv_params& P) {
             }
         }
         __syncthreads();
-        conv_stats_store<NT>(P, bstat, nt0, smem);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(int*)P.stats = (int)gridDim.x;      // header: slots in use
+        float* st = P.stats + CHAP_STATS_HDR + (long)blockIdx.x * 2 * P.Cout;
+        for (int i = threadIdx.x; i < 2 * 16 * NT; i += 256) {
+            const int which = i / (16 * NT), kk = i % (16 * NT);
+            const int nl = nt0 * 16 + kk;
+            const float v = (bstat[(0 * 2 + which) * 16 * NT + kk] + bstat[(1 * 2 + which) * 16 * NT + kk]) + (bstat[(2 * 2 + which) * 16 * NT + kk] + bstat[(3 * 2 + which) * 16 * NT + kk]);
+            if (nl < P.Cout) st[which * P.Cout + nl] = v;
+        }
     }
 }

@@ -9,7 +9,6 @@ static int conv_wp_launch(const chap_conv_params* p, hipStream_t stream) {
     constexpr int MINW = KC == 16 ? (NT == 1 ? 4 : 3) : 2;      // waves per SIMD the registers allow without spilling (128 / 168 / 256 VGPRs)
     const void* kern = chap_kernel<chap_conv_params, conv_wp_kernel<KC, NT, LANESEL>, 256, MINW>();
     const size_t lds = conv_wp_lds_bytes<KC, NT>();
-    if (conv_fin_lds_bytes(p) > lds) { chap_set_error("conv(wp): %zu B of LDS for the in-launch finalize, the kernel has %zu", conv_fin_lds_bytes(p), lds); return CHAP_EUNSUPPORTED; }
     static std::atomic<int> attr_set[16];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;

@@ -6,7 +6,6 @@
 #include "common.h"
 #include "launch.h"
 #include "actbwd_math.h"
-#include "tail.h"
 
 // Index decoding uses 32-bit unsigned arithmetic (64-bit integer division costs ~100 VALU instructions on
 // gfx950 and turned these streaming kernels VALU-bound); entry points reject tensors with >= 2^32 elements.
@@ -684,23 +683,9 @@ __device__ __forceinline__ void act_bwd_kernel(const chap_act_bwd_params& P) {
         }
         __syncthreads();
         float* dst = P.sums + (long)(1 + blockIdx.x) * 2 * C;
-        const bool tail = P.tail_tickets != nullptr;             // in-launch totals (tail.h): the rows leave with write-through stores
         for (int i = threadIdx.x; i < 2 * C; i += 256) {
             const int which = i / C, c = i % C;
-            const float v = (red[(0 * 2 + which) * C + c] + red[(1 * 2 + which) * C + c]) + (red[(2 * 2 + which) * C + c] + red[(3 * 2 + which) * C + c]);
-            if (tail) tail_store(dst + i, v); else dst[i] = v;
-        }
-        if (tail) {
-            // the block that arrives last does what act_bwd_sum_kernel does: row 0 = totals, dgamma / dbeta accumulated.  LDS: `red` is free
-            // behind tail_total's first barrier (fp64 totals [2C] = 4C floats of its 8C, then the flag)
-            double* tot = (double*)red;
-            if (tail_total<256>(P.sums + 2 * C, 2 * C, (int)gridDim.x, (int)blockIdx.x, 1, P.tail_tickets, P.tail_rows, tot, (int*)(red + 4 * C))) {
-                for (int i = threadIdx.x; i < 2 * C; i += 256) {
-                    const float v = (float)tot[i];
-                    P.sums[i] = v;
-                    if (i < C) { if (P.dbeta) P.dbeta[i] += v; } else if (P.dgamma) P.dgamma[i - C] += v;
-                }
-            }
+            dst[i] = (red[(0 * 2 + which) * C + c] + red[(1 * 2 + which) * C + c]) + (red[(2 * 2 + which) * C + c] + red[(3 * 2 + which) * C + c]);
         }
     }
 }
@@ -754,7 +739,6 @@ static int act_bwd_blocks(const chap_act_bwd_params* p) {
 extern "C" int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream) {
     int r = act_bwd_check(p); if (r) return r;
     CHAP_CHECK_ARG(p->bn && p->mean && p->invstd && p->sums, "chap_act_bwd_reduce: needs bn, mean, invstd, sums");
-    CHAP_CHECK_ARG((p->tail_tickets == nullptr) == (p->tail_rows == nullptr), "chap_act_bwd_reduce: tail_tickets and tail_rows come together");
     const size_t lds = 4 * 2 * p->r.C * sizeof(float);
     const int nb = act_bwd_blocks(p);              // one partial row per block
     if (p->dtype == CHAP_BF16) r = chap_launch<chap_act_bwd_params, act_bwd_kernel<bf16_t, false>, 256>(dim3(nb), dim3(256), lds, (hipStream_t)stream, *p, "chap_act_bwd_reduce");
@@ -763,7 +747,6 @@ extern "C" int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream) {
 #ifdef CHAP_LAB      // lab builds only: timing bound, wrong numerics
     { static int skip = -1; if (skip < 0) skip = getenv("CHAP_LAB_SKIP_ACTSUM") ? 1 : 0; if (skip) return CHAP_OK; }
 #endif
-    if (p->tail_tickets) return CHAP_OK;            // the reduce launch totalled its own rows (tail.h)
     const act_bwd_sum_args sa = {p->sums, nb, p->dgamma, p->dbeta, p->r.C};
     return chap_launch<act_bwd_sum_args, act_bwd_sum_kernel, 256>(dim3(cdiv(2 * p->r.C, 4)), dim3(256), 0, (hipStream_t)stream, sa, "chap_act_bwd_reduce(sum)");
 }

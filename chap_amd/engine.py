@@ -292,26 +292,6 @@ class Executor:
         nstat = sum(ops.stats_size(clog(op)) for op in prog.ops if (op.bn and train) or op.inorm)
         arena = L.hold_empty(nstat + nbn * 4, dtype=torch.float32, device=dev)
         apos = 0
-        # in-launch BatchNorm finalize (csrc/tail.h): the ticket words of every layer zeroed by ONE fill at the start of the pass, fp64 group rows beside
-        fin_on = train and ops.in_launch_totals()
-        if fin_on:
-            bn_ops = [op for op in prog.ops if op.bn]
-            fin_tickets = L.hold(torch.zeros(max(len(bn_ops), 1) * L.TAIL_TICKETS, dtype=torch.int32, device=dev))
-            fin_rows = L.hold_empty(sum(ops.tail_rows_size(2 * clog(op)) for op in bn_ops) or 1, dtype=torch.float64, device=dev)
-        fpos = [0, 0]
-
-        def take_fin(op, affine, cnt):
-            """The finalize of `op`'s BatchNorm as part of its conv launch (None: the separate chap_bn_finalize launch)."""
-            if not fin_on:
-                return None
-            n = ops.tail_rows_size(2 * clog(op))
-            t, r = fin_tickets[fpos[0]:fpos[0] + L.TAIL_TICKETS], fin_rows[fpos[1]:fpos[1] + n]
-            fpos[0] += L.TAIL_TICKETS
-            fpos[1] += n
-            upd = update_stats
-            return ops.BnFinalize(t, r, sd[op.bn + ".weight"], sd[op.bn + ".bias"],
-                                  sd[op.bn + ".running_mean"] if upd else None, sd[op.bn + ".running_var"] if upd else None,
-                                  sd.get(op.bn + ".num_batches_tracked") if upd else None, cnt, BN_EPS, BN_MOMENTUM if upd else 0.0, affine)
         # shift of the statistics' moments (sum(x - c), sum((x - c)^2)): a pass-private snapshot of the running means, so
         # that the conv and its finalize see the same c whatever another stream's pass does to the running statistics
         rm_flat, rm_off = self.m._running_mean_flat() if train else (None, None)
@@ -388,9 +368,6 @@ class Executor:
                 o = rm_off[op.bn]
                 sshift = shift_snap[o:o + op.cout]
             bias = sd[op.b] if op.b else None
-            # training-mode BatchNorm: (scale, shift, mean, invstd) as one [4, C] slice -- the conv launch's last block writes them (take_fin)
-            aff4 = take(4 * op.cout) if (op.bn and train) else None
-            fin = None
             if k == "c1":
                 gd = (D, H, W)
                 out = L.hold_empty(n, D, H, W, op.cout, dtype=dtype, device=dev)
@@ -399,9 +376,8 @@ class Executor:
                     ops.planar_to_cl(x, xpad, cpad=16)
                     S.xpad = xpad
                     wp = self._pack(op, L.PACK_CONV_FWD, dtype, sd)
-                    fin = take_fin(op, aff4, n * D * H * W) if aff4 is not None else None
                     ops.conv_fwd([Lazy(xpad)], wp, bias, op.cout, out, grid=(n,) + gd, in_dims=gd, ksize=3, stride=1, dims=dims,
-                                 stats=stats, stats_shift=sshift, fin=fin)
+                                 stats=stats, stats_shift=sshift)
                 else:
                     ops.conv_c1_fwd(x.view(n, D, H, W), sd[op.w], bias, out, dims=dims, stats=stats, stats_shift=sshift)
             else:
@@ -425,15 +401,13 @@ class Executor:
                 if k == "deconv":
                     od = (2 * gd[0] if dims == 3 else gd[0], 2 * gd[1], 2 * gd[2])
                     out = L.hold_empty((n,) + od + (op.cout,), dtype=dtype, device=dev)
-                    fin = take_fin(op, aff4, n * od[0] * od[1] * od[2]) if aff4 is not None else None
                     ops.conv_fwd(srcs, wp, bias, (2 ** dims) * op.cout, out, grid=(n,) + gd, in_dims=ind, ksize=1, stride=1, dims=dims,
-                                 combine=op.combine, out_mode=1, out_cn=op.cout, stats=stats, stats_shift=sshift, fin=fin)
+                                 combine=op.combine, out_mode=1, out_cn=op.cout, stats=stats, stats_shift=sshift)
                     gd = od
                 else:
                     out = L.hold_empty((n,) + gd + (op.cout,), dtype=dtype, device=dev)
-                    fin = take_fin(op, aff4, n * gd[0] * gd[1] * gd[2]) if aff4 is not None else None
                     ops.conv_fwd(srcs, wp, bias, op.cout, out, grid=(n,) + gd, in_dims=ind, ksize=ks, stride=st, dims=dims,
-                                 combine=op.combine, stats=stats, stats_shift=sshift, fin=fin)
+                                 combine=op.combine, stats=stats, stats_shift=sshift)
             vdims[op.out] = gd
             if op.inorm:            # InstanceNorm3d (affine=False) + ReLU: statistics of this single sample
                 scale, shift = take(op.cout), take(op.cout)
@@ -443,20 +417,18 @@ class Executor:
                 ops.bn_finalize(stats, one, zero, None, None, None, gd[0] * gd[1] * gd[2], BN_EPS, 0.0, scale, shift)
                 lz = Lazy(out, scale, shift, True, 0.0)
             elif op.bn:
+                scale, shift = take(op.cout), take(op.cout)
                 if train:
-                    c_ = op.cout
-                    scale, shift, mean, invstd = aff4[:c_], aff4[c_:2 * c_], aff4[2 * c_:3 * c_], aff4[3 * c_:]
+                    mean, invstd = take(op.cout), take(op.cout)
                     cnt = n * gd[0] * gd[1] * gd[2]
                     upd = update_stats
-                    if fin is None:             # (the conv launch did not finalize: CHAP_TAIL=0, or the scalar first-layer kernel)
-                        ops.bn_finalize(stats, sd[op.bn + ".weight"], sd[op.bn + ".bias"],
-                                        sd[op.bn + ".running_mean"] if upd else None, sd[op.bn + ".running_var"] if upd else None,
-                                        sd.get(op.bn + ".num_batches_tracked") if upd else None,
-                                        cnt, BN_EPS, BN_MOMENTUM if upd else 0.0, scale, shift, mean, invstd,
-                                        stats_shift=sshift, clog=clog(op))
+                    ops.bn_finalize(stats, sd[op.bn + ".weight"], sd[op.bn + ".bias"],
+                                    sd[op.bn + ".running_mean"] if upd else None, sd[op.bn + ".running_var"] if upd else None,
+                                    sd.get(op.bn + ".num_batches_tracked") if upd else None,
+                                    cnt, BN_EPS, BN_MOMENTUM if upd else 0.0, scale, shift, mean, invstd,
+                                    stats_shift=sshift, clog=clog(op))
                     S.bnstat[op.bn] = (mean, invstd, cnt)
                 else:
-                    scale, shift = take(op.cout), take(op.cout)
                     ops.bn_eval_affine(sd[op.bn + ".weight"], sd[op.bn + ".bias"], sd[op.bn + ".running_mean"], sd[op.bn + ".running_var"],
                                        BN_EPS, scale, shift)
                 lz = Lazy(out, scale, shift, True, op.slope)
@@ -585,23 +557,6 @@ class Executor:
             spos[0] += n
             return t
 
-        # in-launch totals (csrc/tail.h): ticket words of every layer zeroed by ONE fill at the start of the pass, fp64 group rows beside them
-        tail_on = ops.in_launch_totals()
-        if tail_on:
-            nbn_ops = sum(1 for op in prog.ops if op.bn)
-            tickets_arena = L.hold(torch.zeros(max(nbn_ops, 1) * L.TAIL_TICKETS, dtype=torch.int32, device=dev))
-            trows_arena = L.hold_empty(sum(ops.tail_rows_size(2 * op.cout) for op in prog.ops if op.bn) or 1, dtype=torch.float64, device=dev)
-        tpos = [0, 0]
-
-        def take_tail(c):
-            if not tail_on:
-                return None
-            n = ops.tail_rows_size(2 * c)
-            t = (tickets_arena[tpos[0]:tpos[0] + L.TAIL_TICKETS], trows_arena[tpos[1]:tpos[1] + n])
-            tpos[0] += L.TAIL_TICKETS
-            tpos[1] += n
-            return t
-
         def scatter(op, srcs, dsrc):
             muls = S.fold.get(op.branch) if S.tables is not None else None
             if not muls:
@@ -676,7 +631,6 @@ class Executor:
                             kw.update(dgamma=gr[op.bn + ".weight"], dbeta=gr[op.bn + ".bias"])
                     if op.bn:
                         kw["sums"] = take_sums(v.C)
-                        kw["tail"] = take_tail(v.C)
                     ops.act_bwd(v, c or [], gout, g_pool=pl[0] if pl else None, pool_idx=pl[1] if pl else None, **kw)
                     g = Lazy(gout)
             # ---- this conv's own backward

@@ -68,10 +68,9 @@ def pack_weights(w, kind, dtype, cin, cout, taps):
 
 def conv_fwd(srcs, wpacked, bias, cout, out, *, grid, in_dims, ksize, stride, dims, combine=0,
              out_ld=None, out_coff=0, out_mode=0, out_cn=0, out_planar=False, out_f32=False,
-             stats=None, stats_shift=None, out2=None, fin=None):
+             stats=None, stats_shift=None, out2=None):
     """stats: fp32 buffer from `stats_buffer(cout)` (per-block partial slots of the shifted moments, chap_hip.h);
-    stats_shift: fp32 [real channels] or None.  out2: a second output tensor taking the channels [out.shape[-1], cout) (chap_conv_params.out2).
-    fin: a `BnFinalize` -- the launch's last block finalizes the BatchNorm itself (chap_conv_params.fin, csrc/tail.h): no bn_finalize call follows."""
+    stats_shift: fp32 [real channels] or None.  out2: a second output tensor taking the channels [out.shape[-1], cout) (chap_conv_params.out2)."""
     p = L.ConvParams()
     for i, s in enumerate(srcs):
         s.fill(p.src[i])
@@ -89,29 +88,7 @@ def conv_fwd(srcs, wpacked, bias, cout, out, *, grid, in_dims, ksize, stride, di
     if out2 is not None:
         assert out2.shape == out.shape and out2.dtype == out.dtype and cout == 2 * out.shape[-1]
         p.out2, p.out2_from = out2.data_ptr(), out.shape[-1]
-    if fin is not None:
-        assert stats is not None
-        fin.fill(p.fin, cout)
     L.call("chap_conv_fwd", p, _stream())
-
-
-class BnFinalize:
-    """The BatchNorm finalize a conv launch is to do itself (chap_bn_fin_t): the arguments of `bn_finalize`, the four outputs as ONE tensor
-    affine [4, C] = (scale, shift, mean, invstd), plus the ticket words (ZERO when the launch starts) and the fp64 scratch of the in-launch total."""
-
-    def __init__(self, tickets, rows, gamma, beta, running_mean, running_var, nbt, count, eps, momentum, affine):
-        self.tickets, self.rows, self.gamma, self.beta = tickets, rows, gamma, beta
-        self.running_mean, self.running_var, self.nbt = running_mean, running_var, nbt
-        self.count, self.eps, self.momentum, self.affine = count, eps, momentum, affine
-
-    def fill(self, f, clog):
-        c = self.gamma.numel()
-        assert self.tickets.dtype == torch.int32 and self.tickets.numel() >= L.TAIL_TICKETS
-        assert self.rows.dtype == torch.float64 and self.rows.numel() >= tail_rows_size(2 * clog)
-        assert self.affine.dtype == torch.float32 and self.affine.numel() == 4 * c and self.affine.is_contiguous() and clog % c == 0
-        f.tickets, f.rows, f.gamma, f.beta = self.tickets.data_ptr(), self.rows.data_ptr(), self.gamma.data_ptr(), self.beta.data_ptr()
-        f.running_mean, f.running_var, f.num_batches_tracked = _p(self.running_mean), _p(self.running_var), _p(self.nbt)
-        f.affine, f.C, f.count, f.eps, f.momentum = self.affine.data_ptr(), c, float(self.count), self.eps, self.momentum
 
 
 def stats_size(clog):
@@ -248,12 +225,10 @@ def _act_bwd_params(lazy, grads, g_pool, pool_idx, mean, invstd, gamma, sums, go
 
 
 def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=None, gamma=None,
-            dgamma=None, dbeta=None, count=1.0, bn_mode=None, sums=None, tail=None):
+            dgamma=None, dbeta=None, count=1.0, bn_mode=None, sums=None):
     """grads: list of (tensor, channel offset).
     bn_mode 1 (default when mean is given): training-mode BN backward fused in;
-    bn_mode 2: fixed affine (eval-mode BN), dgamma/dbeta from the same reduction when requested.
-    tail: (tickets, rows) from `tail_buffers` -- the reduce launch totals its own partial rows (csrc/tail.h) instead of a second kernel;
-    the tickets must be ZERO when the launch starts."""
+    bn_mode 2: fixed affine (eval-mode BN), dgamma/dbeta from the same reduction when requested."""
     if bn_mode is None:
         bn_mode = 1 if mean is not None else 0
     need_reduce = bn_mode == 1 or (bn_mode == 2 and (dgamma is not None or dbeta is not None))
@@ -261,25 +236,10 @@ def act_bwd(lazy, grads, gout, *, g_pool=None, pool_idx=None, mean=None, invstd=
         sums = L.hold_empty(act_bwd_sums_size(lazy.C), dtype=torch.float32, device=gout.device)
     p = _act_bwd_params(lazy, grads, g_pool, pool_idx, mean, invstd, gamma, sums, gout, dgamma, dbeta, count)
     p.bn = bn_mode
-    if tail is not None and need_reduce:
-        assert tail[0].dtype == torch.int32 and tail[0].numel() >= L.TAIL_TICKETS and tail[1].dtype == torch.float64 and tail[1].numel() >= tail_rows_size(2 * lazy.C)
-        p.tail_tickets, p.tail_rows = tail[0].data_ptr(), tail[1].data_ptr()
     if need_reduce:
         L.call("chap_act_bwd_reduce", p, _stream())
     L.call("chap_act_bwd_apply", p, _stream())
     return sums
-
-
-def tail_rows_size(width):
-    """doubles of the second-level scratch of an in-launch total over rows of `width` floats (csrc/tail.h)."""
-    return L.TAIL_GROUPS * width
-
-
-def in_launch_totals():
-    """CHAP_TAIL (A/B switch, default 1): BatchNorm statistics and BatchNorm-backward sums are totalled by the launch that produces them (the block
-    that arrives last finishes: csrc/tail.h) instead of by bn_finalize / act_bwd_sum launches."""
-    import os
-    return os.environ.get("CHAP_TAIL", "1") != "0"
 
 
 def act_bwd_sums_size(c):

@@ -42,8 +42,6 @@
  *      stream: +15-22 % step time), the "lazy gradient" chap_bgrad_t of chap_wgrad (+0.8 / +2.7 %), the deferred multi-layer slab reduction
  *      (+-0 / +1 %); measurements in DESIGN.md section 5.  chap_conv_params.out2 / out2_from (a concat layer's input gradient as two dense
  *      tensors).
- *   8  in-launch totals (csrc/tail.h): chap_conv_params.fin (BatchNorm finalize by the conv launch's last block), chap_act_bwd_params.tail_tickets /
- *      tail_rows (BatchNorm-backward totals by the reduce launch's last block); CHAP_TAIL_*.
  */
 #ifndef CHAP_HIP_H
 #define CHAP_HIP_H
@@ -55,12 +53,9 @@
 extern "C" {
 #endif
 
-#define CHAP_ABI_VERSION 8
+#define CHAP_ABI_VERSION 7
 #define CHAP_STATS_MAX_SLOTS 1024  /* per-block partial slots of the BatchNorm statistics (one per persistent conv block) */
 #define CHAP_STATS_HDR 4           /* floats in front of the slots; word 0 = number of slots in use (int32)                */
-#define CHAP_TAIL_GROUP   32      /* in-launch totals (csrc/tail.h): partial rows per first-level group ...                  */
-#define CHAP_TAIL_GROUPS  32      /* ... groups (32 x 32 = 1024 rows = CHAP_STATS_MAX_SLOTS = CHAP_ACT_BWD_SLOTS)            */
-#define CHAP_TAIL_TICKETS 64      /* int32 ticket words per launch: [0] second level, [1 + g] group g; the rest padding      */
 #define CHAP_ACT_BWD_SLOTS 1024    /* per-block partial slots of the BN-backward sums                                      */
 #define CHAP_LOSS_SLOTS 512        /* per-block partial rows of the loss accumulators                                      */
 #define CHAP_CHANSUM_SLOTS 512
@@ -101,19 +96,6 @@ typedef struct {
  *                 E[x^2] - E[x]^2; NULL = 0).  Buffer: CHAP_STATS_HDR + CHAP_STATS_MAX_SLOTS * 2 * Cout floats.
  *                 chap_bn_finalize sums the slots in a fixed order: bitwise reproducible for a given launch geometry.
  */
-/* ABI 8 -- BatchNorm finalize INSIDE the launch that produces the statistics (csrc/tail.h).  The conv's blocks store their partial slots as
- * before; the block that arrives last (two ticket levels, CHAP_TAIL_GROUP slots per group) totals them in fp64 in a fixed order and does what
- * chap_bn_finalize does: scale / shift of the lazy activation, saved mean / invstd, running statistics.  One launch and one launch gap less on
- * the dependency chain per BatchNorm layer (~150 of the ~740 launches of a 2D training iteration, with the BatchNorm-backward totals). */
-typedef struct {
-    int32_t* tickets;          /* CHAP_TAIL_TICKETS int32, ZERO when the launch starts (the caller zeroes them: one memset per pass); NULL = off */
-    double*  rows;             /* CHAP_TAIL_GROUPS x 2 x Cout fp64 scratch, nothing to zero                                                     */
-    const float* gamma;  const float* beta;
-    float* running_mean; float* running_var; int64_t* num_batches_tracked;     /* as chap_bn_finalize_params (NULL / momentum 0: not updated)   */
-    float* affine;             /* out [4][C]: scale, shift, mean, invstd                                                                        */
-    int32_t C;  float count;  float eps;  float momentum;                      /* C real channels (Cout = C x sub-positions of a transposed conv) */
-} chap_bn_fin_t;
-
 typedef struct {
     chap_src_t  src[2];
     int32_t     nsrc;          /* 1 or 2                                                          */
@@ -140,10 +122,6 @@ typedef struct {
     void*       out2;          /* input gradient of a layer whose input was torch.cat((a, b), 1) (unet.py:98) as two DENSE tensors: the consumers of a  */
                                /* half (BatchNorm backward) read whole sectors instead of a 16-channel slice of 32-channel rows.  Same out_ld / out_coff; */
                                /* out_mode 0, channel-last, out2_from % 16 == 0; NULL = off                                                             */
-    chap_bn_fin_t fin;         /* ABI 8: BatchNorm finalize inside this launch (fin.tickets != NULL; needs stats): no chap_bn_finalize call follows       */
-#ifdef CHAP_CONV_PAD           /* lab builds only (kernel-argument size experiment, tools/lab): never defined in the product build */
-    char        lab_pad[CHAP_CONV_PAD];
-#endif
 } chap_conv_params;
 
 int chap_conv_fwd(const chap_conv_params* p, void* stream);
@@ -269,10 +247,6 @@ typedef struct {
     float* dgamma; float* dbeta;                     /* accumulated (+=)                          */
     int32_t N, D, H, W;  int32_t bn;  /* 0 none, 1 training-mode BN, 2 fixed affine (eval BN): g = dz*scale */
     float count;  int32_t dtype;
-    /* ABI 8, in-launch totals (csrc/tail.h): with both set, chap_act_bwd_reduce is ONE launch -- the block that arrives last totals the partial rows,
-     * writes row 0 and accumulates dgamma / dbeta itself (no second kernel).  NULL = the two-launch form. */
-    int32_t* tail_tickets;  /* CHAP_TAIL_TICKETS int32, ZERO when the launch starts (the caller zeroes them: one memset for all layers of a pass)        */
-    double*  tail_rows;     /* CHAP_TAIL_GROUPS x 2C fp64 scratch, nothing to zero                                                                        */
 } chap_act_bwd_params;
 int chap_act_bwd_reduce(const chap_act_bwd_params* p, void* stream);
 int chap_act_bwd_apply(const chap_act_bwd_params* p, void* stream);

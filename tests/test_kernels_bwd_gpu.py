@@ -119,45 +119,6 @@ def test_act_bn_backward_with_pool(dtype):
     assert relerr(dgamma, gm.grad) < tol and relerr(dbeta, bt.grad) < tol
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 12, 16), (3, 64, 40, 40), (4, 16, 128, 128), (2, 256, 16, 16)])
-def test_act_bn_backward_in_launch_totals(shape):
-    """chap_act_bwd_reduce with tail_tickets / tail_rows (the block that arrives last totals the partial rows: csrc/tail.h) against the two-launch
-    form: 6 rows (one group, one hop), 150 rows (5 groups, the last one short), 512 rows (16 groups), 256 channels.  Repeated with fresh tickets:
-    which block arrives last changes from run to run, the totals must not."""
-    g = torch.Generator().manual_seed(31)
-    N, C, H, W = shape
-    dtype = torch.bfloat16
-    raw = rq(torch.randn(N, C, H, W, generator=g) * 1.5 + 0.3, dtype)
-    gamma = torch.rand(C, generator=g) + 0.5
-    g1 = rq(torch.randn(N, C, H, W, generator=g), dtype)
-    mean = raw.mean((0, 2, 3)); invstd = (raw.var((0, 2, 3), unbiased=False) + 1e-5).rsqrt()
-    scale = gamma * invstd; shift = -mean * scale
-    lz = ops.Lazy(cl(raw, dtype), scale.to(DEV), shift.to(DEV), True, 0.01)
-    gin = cl(g1, dtype)
-
-    def run(tail):
-        gout = torch.empty(N, 1, H, W, C, device=DEV, dtype=dtype)
-        dgamma, dbeta = torch.full((C,), 0.5, device=DEV), torch.full((C,), -0.25, device=DEV)
-        sums = torch.full((ops.act_bwd_sums_size(C),), float("nan"), device=DEV)
-        ops.act_bwd(lz, [(gin, 0)], gout, mean=mean.to(DEV), invstd=invstd.to(DEV), gamma=gamma.to(DEV), dgamma=dgamma, dbeta=dbeta, count=N * H * W,
-                    sums=sums, tail=tail)
-        return gout, dgamma, dbeta, sums[:2 * C].clone()
-
-    ref = run(None)
-    assert torch.isfinite(ref[3]).all()
-    for rep in range(12):
-        tickets = torch.zeros(L.TAIL_TICKETS, dtype=torch.int32, device=DEV)
-        rows = torch.full((ops.tail_rows_size(2 * C),), float("nan"), dtype=torch.float64, device=DEV)
-        got = run((tickets, rows))
-        # the two forms add the same fp32 rows in fp64 in different orders: the float totals agree to the last place or the one beside it
-        assert torch.allclose(got[3], ref[3], rtol=3e-7, atol=0), (rep, (got[3] - ref[3]).abs().max())
-        assert torch.allclose(got[1], ref[1], rtol=3e-7, atol=1e-7) and torch.allclose(got[2], ref[2], rtol=3e-7, atol=1e-7)
-        assert relerr(got[0].float(), ref[0].float()) < 1e-6
-        if rep:
-            assert all(torch.equal(a, b) for a, b in zip(got, first)), "in-launch totals differ between runs"
-        first = got
-
-
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("dims", [2, 3])
 def test_first_conv_backward(dtype, dims):

@@ -549,87 +549,3 @@ def test_conv_wave_private_2d(cins, cout, hw, keep, split, monkeypatch):
     assert relerr(got["1"][1], got["0"][1]) < 1e-4
     rc = ref - cshift.view(1, -1, 1, 1)
     assert relerr(got["1"][1][0], rc.sum((0, 2, 3))) < 1e-3 + TOL[dtype]
-
-
-@pytest.mark.parametrize("case", ["wp16_big", "wp16_ragged", "wp32_two_sources", "deep2d", "kpar3d", "bricks3d", "deconv2d", "deconv3d", "fp32_2d"])
-def test_conv_finalizes_its_batchnorm(case):
-    """chap_conv_params.fin (csrc/tail.h): the conv launch's last block totals the partial statistics slots (two ticket levels) and does what
-    chap_bn_finalize does -- against the two-launch form, on every kernel family that writes statistics (wave-private 2D, conv_fwd_kernel 2D / 3D
-    bricks, K-parallel 3D, the transposed convs with their sub-lattice rows), from 8 slots (one hop) to 1024 (32 groups).  Repeated with fresh
-    tickets: which block arrives last changes from run to run, the result must not."""
-    g = torch.Generator().manual_seed(71)
-    dtype = torch.float32 if case == "fp32_2d" else torch.bfloat16
-    dims, ks, deconv = 2, 3, False
-    if case == "wp16_big":
-        N, cins, cout, sp = 4, [16], 16, (1, 256, 256)
-    elif case == "wp16_ragged":
-        N, cins, cout, sp = 3, [16], 32, (1, 37, 52)
-    elif case == "wp32_two_sources":
-        N, cins, cout, sp = 2, [16, 16], 16, (1, 64, 80)
-    elif case == "deep2d":
-        N, cins, cout, sp = 6, [128], 128, (1, 32, 32)
-    elif case == "kpar3d":
-        N, cins, cout, sp, dims = 2, [128], 128, (10, 14, 14), 3
-    elif case == "bricks3d":
-        N, cins, cout, sp, dims = 1, [16], 16, (20, 28, 28), 3
-    elif case == "deconv2d":
-        N, cins, cout, sp, ks, deconv = 3, [64], 32, (1, 20, 24), 1, True
-    elif case == "deconv3d":
-        N, cins, cout, sp, dims, ks, deconv = 1, [32], 16, (6, 10, 12), 3, 1, True
-    else:
-        N, cins, cout, sp = 2, [32], 32, (1, 40, 36)
-    D, H, W = sp
-    cin = sum(cins)
-    lazies = []
-    for c in cins:
-        x = rq(torch.randn(N, c, D, H, W, generator=g), dtype)
-        sc, sh = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.2
-        lazies.append(ops.Lazy(cl(x, dtype) if dims == 3 else cl(x[:, :, 0], dtype), sc.to(DEV), sh.to(DEV), True, 0.01))
-    nsub = (2 ** dims) if deconv else 1
-    if deconv:
-        w = torch.randn(cin, cout, *([2] * dims), generator=g) / cin ** 0.5
-        wp = ops.pack_weights(w.to(DEV), L.PACK_DECONV_FWD, dtype, cin, cout, nsub)
-        od = (2 * D if dims == 3 else D, 2 * H, 2 * W)
-    else:
-        w = torch.randn(cout, cin, *([3] * dims), generator=g) / (cin * 3 ** dims) ** 0.5
-        wp = ops.pack_weights(w.to(DEV), L.PACK_CONV_FWD, dtype, cin, cout, 3 ** dims)
-        od = (D, H, W)
-    clog = cout * nsub
-    b = torch.randn(cout, generator=g).to(DEV)
-    gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(DEV), torch.randn(cout, generator=g).to(DEV)
-    rm0, rv0 = (torch.randn(cout, generator=g) * 0.1).to(DEV), (torch.rand(cout, generator=g) + 0.5).to(DEV)
-    cshift = rm0.clone()
-    cnt = N * od[0] * od[1] * od[2]
-
-    def run(fused):
-        out = torch.full((N,) + od + (cout,), float("nan"), device=DEV, dtype=dtype)
-        stats = ops.stats_buffer(clog, DEV)
-        aff = torch.full((4, cout), float("nan"), device=DEV)
-        rm, rv, nbt = rm0.clone(), rv0.clone(), torch.zeros((), dtype=torch.long, device=DEV)
-        fin = None
-        if fused:
-            tickets = torch.zeros(L.TAIL_TICKETS, dtype=torch.int32, device=DEV)
-            rows = torch.full((ops.tail_rows_size(2 * clog),), float("nan"), dtype=torch.float64, device=DEV)
-            fin = ops.BnFinalize(tickets, rows, gamma, beta, rm, rv, nbt, cnt, 1e-5, 0.1, aff)
-        kw = dict(out_mode=1, out_cn=cout) if deconv else {}
-        ops.conv_fwd(lazies, wp, b, clog, out, grid=(N, D, H, W), in_dims=(D, H, W), ksize=ks, stride=1, dims=dims, stats=stats, stats_shift=cshift, fin=fin, **kw)
-        if not fused:
-            ops.bn_finalize(stats, gamma, beta, rm, rv, nbt, cnt, 1e-5, 0.1, aff[0], aff[1], aff[2], aff[3], stats_shift=cshift, clog=clog)
-        torch.cuda.synchronize()
-        return out, aff, rm, rv, int(nbt), int(stats[:1].view(torch.int32).item())
-
-    ref = run(False)
-    assert torch.isfinite(ref[1]).all() and ref[4] == 1
-    first = None
-    for rep in range(8):
-        got = run(True)
-        assert torch.equal(got[0], ref[0]) and got[4] == 1 and got[5] == ref[5]
-        for a, r in zip(got[1:4], ref[1:4]):
-            assert torch.allclose(a, r, rtol=2e-6, atol=1e-7), (case, rep, (a - r).abs().max())
-        if first is not None:
-            assert all(torch.equal(a, f) for a, f in zip(got[1:4], first[1:4])), "the in-launch finalize differs between runs"
-        first = got
-    # against torch: batch statistics of the conv output (channel-last -> NCDHW)
-    y = uncl(ref[0]).float() if dims == 3 else uncl(ref[0]).squeeze(2).float()
-    mean = y.mean(tuple(i for i in range(y.dim()) if i != 1))
-    assert relerr(first[1][2], mean) < (1e-4 if dtype == torch.float32 else 2e-2)
