@@ -6,6 +6,7 @@
 #include "common.h"
 #include "launch.h"
 #include "actbwd_math.h"
+#include "conv_c1_mfma.h"
 
 // Index decoding uses 32-bit unsigned arithmetic (64-bit integer division costs ~100 VALU instructions on
 // gfx950 and turned these streaming kernels VALU-bound); entry points reject tensors with >= 2^32 elements.
@@ -84,6 +85,23 @@ extern "C" int chap_conv_c1_fwd(const chap_conv_c1_params* p, void* stream) {
     dim3 grid((unsigned)(cdiv(npix, 256) < CHAP_STATS_MAX_SLOTS ? cdiv(npix, 256) : CHAP_STATS_MAX_SLOTS));   // one statistics slot per block
     hipStream_t s = (hipStream_t)stream;
     const bool d3 = p->dims == 3, bf = p->dtype == CHAP_BF16;
+    if (bf) {
+        // bf16: the taps as the K dimension of one MFMA per 16 pixels (conv_c1_mfma.h).  CHAP_C1_MFMA=0 (lab knob): the scalar kernel below.
+        static int mf = -1;
+        if (mf < 0) { const char* e = getenv("CHAP_C1_MFMA"); mf = (e && atoi(e) == 0) ? 0 : 1; }
+        if (mf) {
+            CHAP_CHECK_ARG(npix < (1l << 31), "chap_conv_c1_fwd: %ld pixels", npix);
+            auto waste = [&](int txt) { const int tx = 16 * txt; return cdiv(p->W, tx) * tx - p->W; };
+            const int txt = waste(5) < waste(4) ? 5 : 4;         // 16-pixel tiles per block row: W = 80 (LA patches) takes 5, powers of two 4
+            const int ty = d3 ? 4 : 8, tz = d3 ? 2 : 1;
+            const long ntiles = (long)p->N * cdiv(p->D, tz) * cdiv(p->H, ty) * cdiv(p->W, 16 * txt);
+            dim3 g((unsigned)(ntiles < CHAP_STATS_MAX_SLOTS ? ntiles : CHAP_STATS_MAX_SLOTS));      // persistent blocks, one statistics slot each
+            if (d3 && txt == 5) return chap_launch<chap_conv_c1_params, conv_c1_mfma_kernel<true, 5>, 256>(g, dim3(256), 0, s, *p, "chap_conv_c1_fwd(mfma)");
+            if (d3) return chap_launch<chap_conv_c1_params, conv_c1_mfma_kernel<true, 4>, 256>(g, dim3(256), 0, s, *p, "chap_conv_c1_fwd(mfma)");
+            if (txt == 5) return chap_launch<chap_conv_c1_params, conv_c1_mfma_kernel<false, 5>, 256>(g, dim3(256), 0, s, *p, "chap_conv_c1_fwd(mfma)");
+            return chap_launch<chap_conv_c1_params, conv_c1_mfma_kernel<false, 4>, 256>(g, dim3(256), 0, s, *p, "chap_conv_c1_fwd(mfma)");
+        }
+    }
     if (bf && d3) return chap_launch<chap_conv_c1_params, conv_c1_fwd_kernel<bf16_t, true, 16>, 256>(grid, dim3(256), 0, s, *p, "chap_conv_c1_fwd");
     if (bf) return chap_launch<chap_conv_c1_params, conv_c1_fwd_kernel<bf16_t, false, 16>, 256>(grid, dim3(256), 0, s, *p, "chap_conv_c1_fwd");
     if (d3) return chap_launch<chap_conv_c1_params, conv_c1_fwd_kernel<float, true, 16>, 256>(grid, dim3(256), 0, s, *p, "chap_conv_c1_fwd");

@@ -129,6 +129,13 @@ def side_branch():
     return 2 if os.environ.get("CHAP_SIDE_DECODER", "1") == "2" else 1
 
 
+def first_conv_direct():
+    """CHAP_C1_DIRECT (lab / A-B switch, default 1): the first conv (one input channel) of a bf16 pass on its own kernel (csrc/conv_c1_mfma.h) instead
+    of the generic conv over the image zero-padded to 16 channels."""
+    import os
+    return os.environ.get("CHAP_C1_DIRECT", "1") != "0"
+
+
 def split_concat_gradient():
     """CHAP_SPLIT_CONCAT (lab / A-B switch, default 1): the input gradient of a concat layer as two dense tensors (chap_conv_params.out2)."""
     import os
@@ -371,7 +378,11 @@ class Executor:
             if k == "c1":
                 gd = (D, H, W)
                 out = L.hold_empty(n, D, H, W, op.cout, dtype=dtype, device=dev)
-                if dtype == torch.bfloat16 or x.shape[1] > 1:     # (in_chns > 1: the padded MFMA path in fp32 too; the scalar kernels are 1-channel)
+                if dtype == torch.bfloat16 and x.shape[1] == 1 and op.cout == 16 and first_conv_direct():
+                    # bf16, one input channel: the taps as the K dimension of one MFMA per 16 pixels (csrc/conv_c1_mfma.h) -- no zero-padded copy of the
+                    # image; the backward pass builds it when (and only when) it needs the weight gradient
+                    ops.conv_c1_fwd(x.view(n, D, H, W), sd[op.w], bias, out, dims=dims, stats=stats, stats_shift=sshift)
+                elif dtype == torch.bfloat16 or x.shape[1] > 1:     # (in_chns > 1: the padded MFMA path in fp32 too; the scalar kernels are 1-channel)
                     xpad = L.hold_empty(n, D, H, W, 16, dtype=dtype, device=dev)
                     ops.planar_to_cl(x, xpad, cpad=16)
                     S.xpad = xpad
@@ -639,6 +650,9 @@ class Executor:
                 gt = g.raw if (g.coff == 0 and g.C == g.ld) else None
                 assert gt is not None
                 if need_wgrad:
+                    if S.xpad is None and dtype == torch.bfloat16:      # the forward ran the direct first-layer kernel: pad the image now
+                        S.xpad = L.hold_empty(n, D, H, W, 16, dtype=dtype, device=dev)
+                        ops.planar_to_cl(S.x, S.xpad, cpad=16)
                     if S.xpad is not None:
                         taps = 3 ** dims
                         cin = S.x.shape[1]

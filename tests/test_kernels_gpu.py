@@ -246,6 +246,41 @@ def test_first_conv_c1(dtype, dims):
     assert relerr(st[1], (rc * rc).sum(red)) < 1e-3
 
 
+@pytest.mark.parametrize("shape", [(12, 1, 256, 256), (3, 1, 37, 90), (2, 56, 112, 80), (1, 9, 21, 70), (1300, 1, 8, 16)])
+def test_first_conv_direct_equals_padded_path(shape):
+    """bf16 first conv on its own kernel (csrc/conv_c1_mfma.h: the taps are the K dimension of one MFMA per 16 pixels) against the path it replaces --
+    the image zero-padded to 16 channels through the generic conv: the same bf16 products in another summation order.  Full-size 2D batch (blocks walk
+    several tiles), ragged 2D, the LA patch size (W = 80: five 16-pixel tiles per row), ragged 3D, more tiles than statistics slots."""
+    g = torch.Generator().manual_seed(61)
+    N, D, H, W = shape
+    dims = 3 if D > 1 else 2
+    dtype = torch.bfloat16
+    x = torch.randn(N, D, H, W, generator=g).to(DEV)
+    taps = 3 ** dims
+    w = (torch.randn(16, 1, *([3] * dims), generator=g) / taps ** 0.5).to(DEV)
+    b, c0 = torch.randn(16, generator=g).to(DEV), torch.randn(16, generator=g).to(DEV)
+    out = torch.full((N, D, H, W, 16), float("nan"), device=DEV, dtype=dtype)
+    stats = ops.stats_buffer(16, DEV)
+    ops.conv_c1_fwd(x, w, b, out, dims=dims, stats=stats, stats_shift=c0)
+    xpad = torch.empty(N, D, H, W, 16, device=DEV, dtype=dtype)
+    ops.planar_to_cl(x.view(N, 1, D, H, W) if dims == 3 else x.view(N, 1, H, W), xpad, cpad=16)
+    wp = ops.pack_weights(torch.cat((w, torch.zeros(16, 15, *([3] * dims), device=DEV)), 1), L.PACK_CONV_FWD, dtype, 16, 16, taps)
+    ref = torch.empty_like(out)
+    stats_ref = ops.stats_buffer(16, DEV)
+    ops.conv_fwd([ops.Lazy(xpad)], wp, b, 16, ref, grid=(N, D, H, W), in_dims=(D, H, W), ksize=3, stride=1, dims=dims, stats=stats_ref, stats_shift=c0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    # equal except where the two fp32 sums (same products, another order) rounded to neighbouring bf16 values: rare, and one place apart
+    diff, mag = (out.float() - ref.float()).abs(), ref.float().abs()
+    assert (diff <= 2.0 ** -7 * mag + 1e-6).all(), (diff / (mag + 1e-6)).max()
+    assert (diff > 0).float().mean().item() < 1e-3
+    a, r = ops.stats_totals(stats, 16), ops.stats_totals(stats_ref, 16)
+    assert relerr(a.float(), r.float()) < 1e-4
+    again = torch.empty_like(out)
+    ops.conv_c1_fwd(x, w, b, again, dims=dims, stats=ops.stats_buffer(16, DEV), stats_shift=c0)
+    assert torch.equal(again, out)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pool_upsample_bnfinalize(dtype):
     g = torch.Generator().manual_seed(7)
