@@ -136,6 +136,13 @@ def first_conv_direct():
     return os.environ.get("CHAP_C1_DIRECT", "1") != "0"
 
 
+def defer_decoder_wgrad():
+    """CHAP_DEFER_WGRAD (lab / A-B switch, default 0): in a backward pass that forks its second decoder, issue the decoders' weight gradients on the forked
+    stream behind both decoders' chains (beside the trunk's backward) instead of inline."""
+    import os
+    return os.environ.get("CHAP_DEFER_WGRAD", "0") == "1"
+
+
 def split_concat_gradient():
     """CHAP_SPLIT_CONCAT (lab / A-B switch, default 1): the input gradient of a concat layer as two dense tensors (chap_conv_params.out2)."""
     import os
@@ -568,6 +575,17 @@ class Executor:
             spos[0] += n
             return t
 
+        # CHAP_DEFER_WGRAD (A/B switch): the weight gradients of the two decoders are not on the path to the join with the trunk; deferred, they are issued
+        # on the forked stream BEHIND both decoders' chains and run beside the trunk's backward, where that stream used to idle
+        deferred = []
+        defer_on = [False]
+
+        def later(op, fn):
+            if defer_on[0] and op.branch != 0:
+                deferred.append(fn)
+            else:
+                fn()
+
         def scatter(op, srcs, dsrc):
             muls = S.fold.get(op.branch) if S.tables is not None else None
             if not muls:
@@ -673,8 +691,8 @@ class Executor:
             if k == "conv":
                 taps = op.ksize ** dims
                 if need_wgrad:
-                    ops.wgrad(srcs, g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
-                              ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid)
+                    later(op, lambda: ops.wgrad(srcs, g, gr[op.w], (1, taps, ctot * taps), grid=(n, sd_, sh_, sw_), in_dims=(sd_, sh_, sw_),
+                                                ksize=op.ksize, stride=1, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None, kn_valid=kn_valid))
                 wp = self._pack(op, L.PACK_CONV_DGRAD, dtype, sd)
                 if (len(srcs) == 2 and op.combine == 0 and op.ksize == 3 and srcs[0].C == srcs[1].C and srcs[0].C % 16 == 0 and S.tables is None
                         and split_concat_gradient()):
@@ -693,8 +711,8 @@ class Executor:
             elif k == "down":
                 gdd = S.dims[op.out]
                 if need_wgrad:
-                    ops.wgrad(srcs, g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
-                              ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None)
+                    later(op, lambda: ops.wgrad(srcs, g, gr[op.w], (1, nsub, ctot * nsub), grid=(n,) + gdd, in_dims=(sd_, sh_, sw_),
+                                                ksize=2, stride=2, dims=dims, combine=op.combine, db=gr[op.b] if op.b else None))
                 wp = self._pack(op, L.PACK_DOWN_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, nsub * ctot, dsrc, grid=(n,) + gdd, in_dims=gdd, ksize=1, stride=1, dims=dims,
@@ -704,10 +722,12 @@ class Executor:
                 fine = S.dims[op.out]
                 if need_wgrad:
                     assert len(srcs) == 1
-                    ops.wgrad([g], srcs[0], gr[op.w], (1, nsub, op.cout * nsub), grid=(n, sd_, sh_, sw_), in_dims=fine,
-                              ksize=2, stride=2, dims=dims)
-                    if op.b:
-                        ops.channel_sum(g, gr[op.b])
+                    def deconv_wgrad():
+                        ops.wgrad([g], srcs[0], gr[op.w], (1, nsub, op.cout * nsub), grid=(n, sd_, sh_, sw_), in_dims=fine,
+                                  ksize=2, stride=2, dims=dims)
+                        if op.b:
+                            ops.channel_sum(g, gr[op.b])
+                    later(op, deconv_wgrad)
                 wp = self._pack(op, L.PACK_DECONV_DGRAD, dtype, sd)
                 dsrc = L.hold_empty(n, sd_, sh_, sw_, ctot, dtype=dtype, device=dev)
                 ops.conv_fwd([g], wp, None, ctot, dsrc, grid=(n, sd_, sh_, sw_), in_dims=fine, ksize=2, stride=2, dims=dims)
@@ -736,6 +756,7 @@ class Executor:
                             bwd_op(op)
             else:
                 sb = side_branch()
+                defer_on[0] = need_wgrad and defer_decoder_wgrad()
                 with torch.cuda.stream(side):
                     for op in rev:
                         if op.branch != 0 and (op.branch >= 2) == (sb == 2):
@@ -743,10 +764,26 @@ class Executor:
                 for op in rev:
                     if op.branch != 0 and (op.branch >= 2) != (sb == 2):
                         bwd_op(op)
-            cur_stream.wait_stream(side)
+                defer_on[0] = False
+            if deferred:
+                # join the CHAINS only; the deferred weight gradients follow on the forked stream (they read gradient tensors of both decoders) and are
+                # joined at the end of the pass
+                chain_done = torch.cuda.Event()
+                chain_done.record(side)
+                main_done = torch.cuda.Event()
+                main_done.record(cur_stream)
+                cur_stream.wait_event(chain_done)
+                side.wait_event(main_done)
+                with torch.cuda.stream(side):
+                    for fn in deferred:
+                        fn()
+            else:
+                cur_stream.wait_stream(side)
             for op in rev:
                 if op.branch == 0:
                     bwd_op(op)
+            if deferred:
+                cur_stream.wait_stream(side)
         else:
             for op in rev:
                 yield [lambda op=op: bwd_op(op)]
