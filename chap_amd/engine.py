@@ -137,10 +137,14 @@ def first_conv_direct():
 
 
 def defer_decoder_wgrad():
-    """CHAP_DEFER_WGRAD (lab / A-B switch, default 0): in a backward pass that forks its second decoder, issue the decoders' weight gradients on the forked
-    stream behind both decoders' chains (beside the trunk's backward) instead of inline."""
+    """CHAP_DEFER_WGRAD (lab / A-B switch, default 1): in a backward pass that forks its second decoder, the decoders' weight gradients are issued on the
+    forked stream BEHIND both decoders' chains -- they are not on the path to the join with the trunk, and the forked stream used to idle during the trunk's
+    backward.  Round 4, three pairs: 2D 6.24 / 6.22 / 6.26 -> 6.09 / 6.09 / 6.11 ms, 3D 14.68 / 14.61 / 14.69 -> 14.64 / 14.60 / 14.51 ms.  Tried on top and
+    removed: the trunk's weight gradients on that stream too, one event per layer (6.6 / 15.3 ms); pass B (grouped decoders on one stream) borrowing the early
+    VAT pass's idle stream for its decoders' weight gradients (7.65 / 17.3 ms: one more chain for the graph executor's queues); the forked decoder's own
+    weight gradients right behind its chain instead of behind both (no difference) -- profiles/r04_defer_wgrad_ab.log."""
     import os
-    return os.environ.get("CHAP_DEFER_WGRAD", "0") == "1"
+    return os.environ.get("CHAP_DEFER_WGRAD", "1") != "0"
 
 
 def split_concat_gradient():
@@ -575,8 +579,10 @@ class Executor:
             spos[0] += n
             return t
 
-        # CHAP_DEFER_WGRAD (A/B switch): the weight gradients of the two decoders are not on the path to the join with the trunk; deferred, they are issued
-        # on the forked stream BEHIND both decoders' chains and run beside the trunk's backward, where that stream used to idle
+        # the weight gradients of the two decoders are not on the path to the join with the trunk: deferred (defer_decoder_wgrad), they are issued on the
+        # forked stream BEHIND both decoders' chains and run beside the trunk's backward, where that stream used to idle.  The closures stay in `deferred`
+        # until this generator ends, i.e. until the streams have joined: they keep the gradient tensors alive (freed earlier, a tensor goes back to the
+        # allocator of ITS stream and is handed out again while the forked stream still reads it)
         deferred = []
         defer_on = [False]
 
