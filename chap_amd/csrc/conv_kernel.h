@@ -68,7 +68,8 @@ __host__ __device__ constexpr size_t conv_lds_fixed_bytes(int NT) {
 }
 
 // Weights that do not fit LDS whole are staged per item (one K-chunk: STEPS x NT fragment blocks) through
-// registers into a double buffer, like the halo -- when that takes <= 14 fragments per thread and fits.
+// registers into an LDS buffer -- when that takes <= 14 fragments per thread and fits (the predicate still counts two
+// buffers, as rounds 1-3 had: the set of staged instances is unchanged).
 template <typename T, int KS, int ST, bool D3, int KC, int NT, int MR, bool ZW>
 __host__ __device__ constexpr bool conv_wstaged() {
     typedef conv_geom<KS, ST, D3, MR, ZW> G;
@@ -376,7 +377,14 @@ __device__ __forceinline__ void tile_coords(long tile, int tiles_x, int tiles_y,
 }
 
 // __launch_bounds__ second argument of the trampoline (launch.h) that runs this body
-template <int KC, bool D3> constexpr int conv_min_waves() { return CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES : (KC == 16 && !D3 ? 3 : 1); }
+// (round 4: 2 instead of 1 for the 3D and the 32-channel-chunk 2D instances.  Unbounded they took 268-350 registers per lane (VGPRs + accumulation registers)
+//  and ONE block fitted a CU whatever its LDS; at 256 two do.  The staged 32-output-channel 3D instances pay 160-330 B per lane of scratch for it.)
+//  The fp32 instances (the parity mode) keep the build of rounds 1-3: no bound, two staged weight buffers.  Both changes leave every conv OUTPUT bit for bit
+//  (profiles/r04_wbuf1_bits.log), but one weight buffer changes a launch's LDS size, hence its persistent grid, hence how the BatchNorm statistics are dealt to
+//  partial slots (5e-9 .. 1e-8 relative in fp32) -- enough to re-roll the rounding noise of the fp32 iteration's loss (config 0: 2.2e-6 -> 1.2e-5 from the fp32
+//  oracle, tests/test_iteration_conditioning_gpu.py), whose bounds are pinned to the grids of round 3.)
+template <int KC, bool D3, typename T = bf16_t> constexpr int conv_min_waves() { return CHAP_CONV_MINWAVES > 1 ? CHAP_CONV_MINWAVES : (KC == 16 && !D3 ? 3 : (sizeof(T) == 2 ? 2 : 1)); }
+template <typename T> constexpr bool conv_one_wbuf() { return sizeof(T) == 2; }      // staged weights: ONE LDS buffer (bf16) / two (fp32)
 
 template <typename T, int KS, int ST, bool D3, int KC, int NT, int MR, bool ADD2, bool WLDS, bool ZW = false, bool ONE = false>
 __device__ __forceinline__ void conv_fwd_kernel(const chap_conv_params& P) {
@@ -391,7 +399,7 @@ __device__ __forceinline__ void conv_fwd_kernel(const chap_conv_params& P) {
     T* halo1 = halo0 + (size_t)G::HP * PS + HALO_DUMMY;
     float* bstat = (float*)(halo1 + (size_t)G::HP * PS + HALO_DUMMY);
     float* aff = bstat + 4 * 2 * 16 * NT;                   // [2 sources][scale | shift][CONV_MAX_AFFINE_C/2]
-    T* wlds = (T*)(aff + 2 * CONV_MAX_AFFINE_C);            // WLDS: all weights; staged mode: two buffers of one K-chunk's weights
+    T* wlds = (T*)(aff + 2 * CONV_MAX_AFFINE_C);            // WLDS: all weights; staged mode: one buffer of one K-chunk's weights
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int px = lane & 15, g = lane >> 4;
@@ -660,7 +668,7 @@ __device__ __forceinline__ void conv_fwd_kernel(const chap_conv_params& P) {
         CHAP_STAMP(1);
         // ---- MFMA over the taps of this chunk
         const T* wc_g = (const T*)P.wpacked + (long)chunk * STEPS * wstep + ((long)nt0 * 64 + lane) * 8;
-        const T* wc_l = wlds + ((long)(WLDS ? chunk : (int)(it & 1)) * STEPS * NT * 64 + lane) * 8;
+        const T* wc_l = wlds + ((long)(WLDS ? chunk : (conv_one_wbuf<T>() ? 0 : (int)(it & 1))) * STEPS * NT * 64 + lane) * 8;      // (staged mode, bf16: ONE buffer, see the commit at the end of the item)
         // software-pipelined: the fragments of step s+1 are requested before the MFMAs of step s are issued, so
         // the LDS (or L2) latency hides behind MR*NT MFMAs instead of preceding every one of them
         auto load_w = [&](int step, F (&wf)[NT]) {
@@ -781,7 +789,17 @@ __device__ __forceinline__ void conv_fwd_kernel(const chap_conv_params& P) {
         //  top of the next item and waits for every outstanding store before it issues the new loads)
         if (!has_next) break;
         halo_commit<T, KC, ADD2, UNITS, !D3, ONE>(R, U, nxt, s0, s1, aff, plain, nn, nchunk, lanesel);
-        wstage_commit((int)((it + 1) & 1));
+        // Staged weights have ONE LDS buffer in bf16 (round 4; rounds 1-3 and fp32: two, like the halo): every wave has to be through with it before it is overwritten -- a
+        // second barrier per item -- but a block then needs 79 instead of 108 KB of LDS (3D bricks, 32 output channels), and together with the 256-register
+        // bound (conv_min_waves) TWO blocks are resident per CU where one was: the 3D 64->64 layer at 28x28x20 (280 blocks on 256 CUs: two rounds of blocks at
+        // one per CU) 32.0 -> 25.6 us when its weights are staged, the 3D step 14.52 -> 14.09 ms, the 2D step 6.09 -> 6.03 (profiles/r04_conv_wst1m2_steps.log;
+        // either change alone: 14.6 / 14.47 ms)
+        if (conv_one_wbuf<T>()) {
+            if (WST) __syncthreads();
+            wstage_commit(0);
+        } else {
+            wstage_commit((int)((it + 1) & 1));
+        }
         chunk = nchunk == nchunks ? 0 : nchunk;
         CHAP_STAMP(4);
         __syncthreads();
