@@ -22,7 +22,17 @@ constexpr int WG_DEPTH = CHAP_WGRAD_DEPTH;      // A fragments (transposing LDS 
 #define CHAP_WGRAD_PSB16 24
 #endif
 // LDS pixel stride of the B tile (elements): 32 (16) channels + padding for the transposing reads
-template <typename T, int BN = WG_BN> __host__ __device__ constexpr int wg_psb() { return sizeof(T) == 2 ? (BN == 16 ? CHAP_WGRAD_PSB16 : 40) : 36; }
+// Round 4 (with conv_min_waves, conv_kernel.h): the bf16 block-tile instances are bounded to 256 registers per lane (unbounded, the 3D bricks with a 32-wide B
+// tile took 277-370 incl. accumulation registers: one wave per SIMD) and the 32-wide B tile is stored without row padding (stride 32 instead of 40 elements:
+// 80 960 instead of 89 152 B of LDS per brick block) -- two blocks per CU where one was.  3D step 14.08 -> 13.96 ms (three pairs), 2D unchanged
+// (profiles/r04_wgrad3d_two_blocks_ab.log, r04_wgrad_two_blocks_2d_ab.log); 512 instead of 256 blocks for these layers: slower (14.32).
+#ifndef CHAP_WGRAD_PSB32
+#define CHAP_WGRAD_PSB32 32        // row stride (elements) of the 32-wide bf16 B tile (40 = padded, rounds 1-3)
+#endif
+#ifndef CHAP_WGRAD_MINW
+#define CHAP_WGRAD_MINW 2          // __launch_bounds__ second argument of the bf16 block-tile weight-gradient instances (1 = unbounded, rounds 1-3)
+#endif
+template <typename T, int BN = WG_BN> __host__ __device__ constexpr int wg_psb() { return sizeof(T) == 2 ? (BN == 16 ? CHAP_WGRAD_PSB16 : CHAP_WGRAD_PSB32) : 36; }
 // scale/shift cache per source: the brick kernels run up to 256 channels per source and keep it small (LDS for a second block per CU)
 template <bool ZW> __host__ __device__ constexpr int wg_affc() { return ZW ? 512 : CONV_MAX_AFFINE_C; }
 
