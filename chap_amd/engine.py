@@ -107,20 +107,6 @@ def drive(gen, stream):
                     f()
 
 
-def issue_interleaved(what=7):
-    """CHAP_ISSUE_INTERLEAVE (lab / A-B switch, bit mask; default 0 = one chain after the other, the order of rounds 1-3): issue the ops of concurrent
-    chains alternately -- 1: ChapStep's phase B / phase V pass by pass, 2: the early VAT pass between pass A's encoder and decoders, 4: the two
-    decoders of a pass op by op.  The issue order is the creation order of a captured graph's nodes, and the ROCm 7.2 graph executor both feeds the
-    nodes to the GPU in that order and maps them onto its hardware queues by it: round 4 measured all three together at 8.35 ms per 2D step against
-    6.53 (the streams no longer overlap: profiles/r04_timeline_untraced_2d_interleaved.json), see DESIGN.md section 5 for the single switches."""
-    import os
-    try:
-        mask = int(os.environ.get("CHAP_ISSUE_INTERLEAVE", "0"))
-    except ValueError:
-        mask = 0
-    return bool(mask & what)
-
-
 def side_branch():
     """CHAP_SIDE_DECODER (lab / A-B switch, default 1): which decoder of a forking pass runs on the forked stream (the other stays on the pass's
     own).  Round 4, two runs each: 2D 6.413 / 6.421 ms with decoder 2 on the fork, 6.385 / 6.407 with decoder 1; 3D 14.82 / 14.70 vs 14.66 / 14.62
@@ -186,7 +172,6 @@ class Executor:
         self._ident = {}           # C -> (ones, zeros) for InstanceNorm (no affine)
         self._sides = {}           # parent stream -> forked stream for the second decoder
         self._capture_sides = {}   # same, for use inside a graph capture (registered by the owner of the capture)
-        self.after_trunk = None    # one-shot callable run between the trunk and the decoders of the NEXT forward pass (ChapStep: issue order, see forward_steps)
         self.has_inorm = any(op.inorm for op in program.ops)
 
     # ---------------------------------------------------------------- parameters
@@ -482,12 +467,6 @@ class Executor:
         for op in prog.ops:
             if op.branch == 0:
                 yield [lambda op=op: run_op(op)]
-        # One-shot hook between the trunk and the decoders: the caller issues ANOTHER chain's work here (ChapStep, CHAP_ISSUE_INTERLEAVE & 2: the early
-        # VAT pass on its own stream).  Only the ISSUE ORDER changes, i.e. the creation order of a captured graph's nodes -- which decides how the ROCm
-        # graph executor places the chains on its queues (see issue_interleaved).
-        hook, self.after_trunk = self.after_trunk, None
-        if hook is not None:
-            hook()
         if perturb is not None:
             # channel-level perturbation (FilterDropout.perform_dropout): every decoder gets its own version of the
             # trunk's values -- a larger batch with per-(sample, channel) multipliers -- and runs on that batch
@@ -506,26 +485,18 @@ class Executor:
             for pair in zipped:
                 yield [lambda op=op: run_dec(op) for op in pair]
         elif side is not None:
-            # two streams: the second decoder's ops first, then the first one's (CHAP_ISSUE_INTERLEAVE & 4, round-4 experiment: alternately, op by op --
-            # neutral: 6.55 vs 6.5 ms)
+            # two streams: the forked decoder's ops are issued first, then the other one's.  (Round 4 tried them alternately, op by op: neutral, 6.55 vs 6.5 ms;
+            # the ISSUE order is the creation order of a captured graph's nodes, by which the ROCm 7.2 graph executor places the chains on its hardware
+            # queues: DESIGN.md section 5, "Issue order" -- any change here has to be measured on the whole iteration.)
             side.wait_stream(cur_stream)
-            if len(branches) == 3 and issue_interleaved(4):
-                for pair in self._zipped():
-                    for op in pair:
-                        if op.branch >= 2:
-                            with torch.cuda.stream(side):
-                                run_dec(op)
-                        else:
-                            run_dec(op)
-            else:
-                sb = side_branch()                  # which decoder goes to the forked stream (default: the second)
-                with torch.cuda.stream(side):
-                    for op in prog.ops:
-                        if op.branch != 0 and (op.branch >= 2) == (sb == 2):
-                            run_dec(op)
+            sb = side_branch()                  # which decoder goes to the forked stream
+            with torch.cuda.stream(side):
                 for op in prog.ops:
-                    if op.branch != 0 and (op.branch >= 2) != (sb == 2):
+                    if op.branch != 0 and (op.branch >= 2) == (sb == 2):
                         run_dec(op)
+            for op in prog.ops:
+                if op.branch != 0 and (op.branch >= 2) != (sb == 2):
+                    run_dec(op)
             cur_stream.wait_stream(side)
         else:
             for op in prog.ops:
@@ -752,25 +723,16 @@ class Executor:
                     yield [lambda op=op: bwd_op(op)]
         elif side is not None:
             side.wait_stream(cur_stream)
-            if nbr == 3 and issue_interleaved(4):          # the two decoders' ops issued alternately (see forward_steps)
-                for pair in reversed(self._zipped()):
-                    for op in pair:
-                        if op.branch >= 2:
-                            with torch.cuda.stream(side):
-                                bwd_op(op)
-                        else:
-                            bwd_op(op)
-            else:
-                sb = side_branch()
-                defer_on[0] = need_wgrad and defer_decoder_wgrad()
-                with torch.cuda.stream(side):
-                    for op in rev:
-                        if op.branch != 0 and (op.branch >= 2) == (sb == 2):
-                            bwd_op(op)
+            sb = side_branch()
+            defer_on[0] = need_wgrad and defer_decoder_wgrad()
+            with torch.cuda.stream(side):
                 for op in rev:
-                    if op.branch != 0 and (op.branch >= 2) != (sb == 2):
+                    if op.branch != 0 and (op.branch >= 2) == (sb == 2):
                         bwd_op(op)
-                defer_on[0] = False
+            for op in rev:
+                if op.branch != 0 and (op.branch >= 2) != (sb == 2):
+                    bwd_op(op)
+            defer_on[0] = False
             if deferred:
                 # join the CHAINS only; the deferred weight gradients follow on the forked stream (they read gradient tensors of both decoders) and are
                 # joined at the end of the pass

@@ -372,35 +372,16 @@ class ChapStep:
         with self._decoder_fork(main):
             ctx = self._phase_a(volume_batch, label_batch, inject)
             if self.concurrent and self.args["adv_noise"]:
-                # Phase B (side stream) and phase V (this stream, the iteration's critical chain).  Default: all of phase B is issued first, then phase V
-                # (the order of rounds 1-3).  CHAP_ISSUE_INTERLEAVE & 1 (round-4 experiment) issues them pass by pass in alternation -- V's power iteration,
-                # B's forward, V's final forward, B's backward, V's final backward: same launches, same streams, bit-identical results, and 8.05 ms per 2D step
-                # instead of 6.5: the ROCm 7.2 graph executor places the chains of a captured graph on its hardware queues by the creation order of the nodes,
-                # and in that order pass B lands on the VAT chain's queue and runs entirely after it ("Issue order").
+                # Phase B (side stream) and phase V (this stream, the iteration's critical chain): all of phase B is issued first, then phase V.  Round 4 tried
+                # issuing them pass by pass in alternation (same launches, same streams, bit-identical results): 8.05 ms per 2D step instead of 6.5 -- the
+                # ROCm 7.2 graph executor places the chains of a captured graph on its hardware queues by the creation order of the nodes, and in that
+                # order pass B lands on the VAT chain's queue and runs entirely after it ("Issue order").
                 self._side.wait_stream(main)
-                gen_v, gen_b = self._phase_v_steps(ctx), self._phase_b_steps(ctx)
-                losses = vat_loss = None
-                done_v = done_b = False
-                from .engine import issue_interleaved
-                if not issue_interleaved(1):                # (default: all of phase B first, the order of rounds 1-3)
-                    with torch.cuda.stream(self._side):
-                        losses, done_b = self._drain(gen_b), True
-                        if self.grad_sync is not None and update and not torch.cuda.is_current_stream_capturing():
-                            self.grad_sync.start_first()
-                while not (done_v and done_b):
-                    if not done_v:
-                        try:
-                            next(gen_v)
-                        except StopIteration as e:
-                            vat_loss, done_v = e.value, True
-                    if not done_b:
-                        with torch.cuda.stream(self._side):
-                            try:
-                                next(gen_b)
-                            except StopIteration as e:
-                                losses, done_b = e.value, True
-                                if self.grad_sync is not None and update and not torch.cuda.is_current_stream_capturing():
-                                    self.grad_sync.start_first()        # bucket 0 is final: its all-reduce runs beside the VAT chain
+                with torch.cuda.stream(self._side):
+                    losses = self._phase_b(ctx)
+                    if self.grad_sync is not None and update and not torch.cuda.is_current_stream_capturing():
+                        self.grad_sync.start_first()        # bucket 0 is final: its all-reduce runs beside the VAT chain
+                vat_loss = self._phase_v(ctx)
                 main.wait_stream(self._side)
             else:
                 losses = self._phase_b(ctx)
@@ -415,7 +396,7 @@ class ChapStep:
     def _fork_ctl(self, bit):
         """CHAP_FORK_MASK (lab / A-B switch, default 14): which passes of the capture's origin stream fork their second decoder onto a stream of its own
         (1 pass A, 2 the power iteration's backward, 4 the VAT forward passes after the first, 8 the final backward); the others run their decoders with
-        grouped launches.  Every fork is one more chain for the graph executor to place on its few hardware queues (see engine.issue_interleaved).
+        grouped launches.  Every fork is one more chain for the graph executor to place on its few hardware queues ("Issue order").
         Round 4, 12 masks on the whole iteration (profiles/r04_issue_order_ab.log): 14 -- pass A, which already shares the GPU with the early VAT pass,
         keeps its decoders on one stream -- 6.469 ms against 6.513 for 15 (three pairs; 3D 14.79 vs 14.81), every other mask slower (0: 6.83 / 15.8)."""
         cs = getattr(self, "_cs_active", None)
@@ -459,27 +440,17 @@ class ChapStep:
         model.prepare_weights()                  # before the streams fork: every pass of the iteration reads the same packed copies
         if a["adv_noise"]:
             if pre is not None:
-                # The early pass runs on its own stream beside pass A and is issued in front of it.  CHAP_ISSUE_INTERLEAVE & 2 (round-4 experiment) issues it
-                # between pass A's encoder and its decoders (Executor.after_trunk) instead: measured slower (6.95 vs 6.5 ms: it then shares a queue with pass A).
+                # The early pass runs on its own stream beside pass A and is issued in FRONT of it (round 4 tried issuing it between pass A's encoder and
+                # its decoders: 6.95 vs 6.5 ms -- it then shares a queue with pass A)
                 pre.wait_stream(main)
-
-                def issue_early_pass():
-                    with torch.enable_grad(), torch.cuda.stream(pre):
-                        ctx["vat_state"] = self.adv_loss.begin(model, volume_batch, B - lbs, inject)
-                from .engine import issue_interleaved
-                if issue_interleaved(2):
-                    model._exec.after_trunk = issue_early_pass
-                else:
-                    issue_early_pass()
+                with torch.enable_grad(), torch.cuda.stream(pre):
+                    ctx["vat_state"] = self.adv_loss.begin(model, volume_batch, B - lbs, inject)
             else:
                 ctx["vat_state"] = self.adv_loss.begin(model, volume_batch, B - lbs, inject)
         # ---- pass A: pseudo labels from both decoders (no grad), train_ours_2D.py:314-330
         self._fork_ctl(1)
         with torch.no_grad():
-            try:
-                pre_ab1, pre_ab2 = model(ctx["uimg_ab"], drop_masks=inject.get("drop_A"))
-            finally:
-                model._exec.after_trunk = None
+            pre_ab1, pre_ab2 = model(ctx["uimg_ab"], drop_masks=inject.get("drop_A"))
             soft1, soft2, pseudo1, pseudo2, knowledge = ops.pseudo_block(pre_ab1, pre_ab2)
         if pre is not None:
             main.wait_stream(pre)
