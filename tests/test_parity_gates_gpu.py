@@ -286,15 +286,18 @@ def _log_dice_gate(rec):
 
 
 # The bf16-vs-fp32 statement is a STATISTIC (round 4, tools/dice_pairs.py -> profiles/r04_dice_pairs.json; 6 seeds, each seed trained in fp32 and in
-# bf16 from the same initial weights, data order, BCP boxes and device-RNG seed, 1 500 iterations at 256 x 256, B = 24):
-#     mean foreground Dice   fp32 0.7466 +- 0.0150 (s.d. 0.037)      bf16 0.7775 +- 0.0023 (s.d. 0.0056)
-#     paired difference bf16 - fp32: +0.031 +- 0.014 (s.d. 0.034), t = 2.23 < 2.57: no bias detectable at the 5 % level -- and its sign is bf16 >= fp32.
-# A single (fp32, bf16) pair is one draw from a distribution with s.d. 0.034, so it cannot carry a 1e-3 claim and is not asserted against one any more
-# (round 3 moved a one-pair bound 0.02 -> 0.037 -> 0.085 behind its measurements).  What a default-suite run CAN detect is a broken bf16 path: the bf16
-# result is tight (s.d. 0.0056 over seeds), so the gate is absolute -- both modes learn, and bf16 stays within 5 s.d. of its measured mean --; the
-# paired statistic itself is re-measured by tools/dice_pairs.py (CHAP_DICE_PAIRS=1 runs it here with the bounds fixed beforehand: |mean paired
-# difference| <= 3 s.e.m. + 0.01 of the recorded statistic, i.e. 0.052).
-DICE_GATE = {"64": dict(B=8, H=64, W=64, iters=1500), "256": dict(B=24, H=256, W=256, iters=1500, bf16_mean=0.7775, bf16_sd=0.0056)}
+# bf16 from the same initial weights, data order, BCP boxes and device-RNG seed, 1 500 iterations at 256 x 256, B = 24).  Measured TWICE in round 4:
+#     start of the round   fp32 0.7466 +- 0.0150 (s.d. 0.037)   bf16 0.7775 +- 0.0023 (s.d. 0.0056)   paired bf16 - fp32 +0.031 +- 0.014, t = 2.23
+#     last tree            fp32 0.7466 +- 0.0150 (unchanged:    bf16 0.7541 +- 0.0165 (s.d. 0.040)    paired bf16 - fp32 +0.0075 +- 0.0066, t = 1.14
+#                          the fp32 kernels were not touched)
+# (t < 2.57: no bias detectable at the 5 % level, both times).  The bf16 kernels changed in between (wave-private kernels, the first conv's own kernel: other
+# summation orders) and with them every bf16 run: the first run's tiny bf16 spread (0.0056) was a property of that build's draws, not of bf16 -- the second
+# has the same seed-to-seed spread as fp32.  A single (fp32, bf16) pair is one draw from a distribution with s.d. 0.016-0.034 and cannot carry a 1e-3 claim
+# (round 3 moved a one-pair bound 0.02 -> 0.037 -> 0.085 behind its measurements).  What a default-suite run CAN detect is a broken bf16 path (Dice 0-0.3):
+# the gate is "the bf16 run learns", 0.62 = the measured bf16 mean minus 3.3 of its seed-to-seed standard deviations; the paired statistic itself is
+# re-measured by tools/dice_pairs.py (CHAP_DICE_PAIRS=1 runs it here with the bounds fixed beforehand: |mean paired difference| <= 3 s.e.m. + 0.01 of the
+# first recorded statistic, i.e. 0.052).
+DICE_GATE = {"64": dict(B=8, H=64, W=64, iters=1500), "256": dict(B=24, H=256, W=256, iters=1500, bf16_mean=0.7541, bf16_sd=0.0404)}
 
 
 @pytest.mark.parametrize("size", ["64", "256"])
@@ -314,7 +317,7 @@ def test_bf16_training_dice_gate(size):
         assert d16.mean() > d32.mean() - 0.05, rec                         # bf16 not materially BELOW fp32 (one pair: no tighter claim, see above)
     else:
         _log_dice_gate(rec)
-        assert d16.mean() > c["bf16_mean"] - 5 * c["bf16_sd"] - 0.01, rec      # 0.7395: five s.d. of the bf16 seed spread below its measured mean
+        assert d16.mean() > c["bf16_mean"] - 3.3 * c["bf16_sd"], rec      # 0.62: 3.3 s.d. of the bf16 seed spread below its measured mean (this seed: 0.771 on the last tree)
 
 
 @pytest.mark.skipif(os.environ.get("CHAP_DICE_PAIRS") != "1", reason="the paired multi-seed statistic (about 5 min): CHAP_DICE_PAIRS=1, or python tools/dice_pairs.py")
